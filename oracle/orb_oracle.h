@@ -1,0 +1,98 @@
+/* orb_oracle.h -- CPU restatement ("oracle") of the ORB front-end hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (the HIP library under
+ * orb_slam2_detailed_comments_amd/) may include, link, load or call anything declared
+ * here.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and
+ * only as the checker / the timed CPU baseline.
+ *
+ * What it restates (all file:line are relative to the reference tree):
+ *   ORBextractor ctor              src/ORBextractor.cc:776-925
+ *   ComputePyramid (fork: padded)  src/ORBextractor.cc:2093-2168
+ *   ComputeKeyPointsOctTree        src/ORBextractor.cc:1424-1601
+ *   DivideNode / DistributeOctTree src/ORBextractor.cc:963-1035, 1050-1417
+ *   IC_Angle / computeOrientation  src/ORBextractor.cc:104-161, 933-952
+ *   computeOrbDescriptor           src/ORBextractor.cc:177-254
+ *   operator()                     src/ORBextractor.cc:1961-2084
+ *   ORBmatcher::DescriptorDistance src/ORBmatcher.cc:2073-2093
+ *   ORBmatcher::ComputeThreeMaxima src/ORBmatcher.cc:2026-2068
+ *   ORBmatcher::SearchForInitialization src/ORBmatcher.cc:570-712
+ *   Frame grid / GetFeaturesInArea src/Frame.cc:432-460, 633-745
+ *   Frame::ComputeStereoMatches    src/Frame.cc:880-1176
+ *
+ * PARITY PINNING: the reference has no tests, fixtures or golden vectors, and the
+ * arithmetic of cv::FAST / cv::resize / cv::copyMakeBorder / cv::GaussianBlur /
+ * cv::fastAtan2 / cvRound lives in OpenCV (un-vendored system dependency, required
+ * version 3.0+, README-tested 2.4.11 and 3.2; CMakeLists.txt:47-53, README.md:103),
+ * which is absent from this image.  Those primitives are restated here from the published
+ * OpenCV 3.2 algorithms (x86-64 SSE2 baseline build, no IPP).  The reference cannot be
+ * built here (needs OpenCV headers+libs) => **parity unpinned** at the OpenCV boundary;
+ * the only reference-held known answers (umax table, vmax/vmin, thresholds; see
+ * tests/test_oracle_kat.py) are checked.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bit-compatible with cv::KeyPoint (28 bytes) */
+typedef struct orc_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+
+enum { ORC_FP_GCC_FMA = 0, ORC_FP_STRICT = 1 };
+
+typedef struct orc_extractor orc_extractor;
+
+/* ---- extractor ---------------------------------------------------------------- */
+orc_extractor *orc_create(int nfeatures, float scale_factor, int nlevels,
+                          int ini_th_fast, int min_th_fast, int fp_mode);
+void orc_destroy(orc_extractor *e);
+/* returns number of keypoints (>=0) or <0: -1 empty image, -3 bad aspect (nIni==0),
+ * -4 capacity too small.  kps/desc may be NULL (cap ignored) to only run the stages. */
+int orc_extract(orc_extractor *e, const uint8_t *img, int w, int h, int stride,
+                orc_keypoint *kps, uint8_t *desc, int cap);
+/* tables (ctor) */
+void orc_get_tables(const orc_extractor *e, float *scale, float *inv_scale, float *sigma2,
+                    float *inv_sigma2, int *features_per_level, int *umax16);
+/* per-stage results of the last orc_extract */
+int orc_level_dims(const orc_extractor *e, int level, int *w, int *h); /* padded dims */
+const uint8_t *orc_level_image(const orc_extractor *e, int level);      /* padded, step=w */
+const uint8_t *orc_level_blur(const orc_extractor *e, int level);       /* NULL if level had 0 kps */
+int orc_level_candidates(const orc_extractor *e, int level, orc_keypoint *out, int cap);
+int orc_level_keypoints(const orc_extractor *e, int level, orc_keypoint *out, int cap);
+/* per-stage wall time (seconds) accumulated since create: pyramid, fast, quadtree, orient, blur, desc */
+void orc_get_stage_times(const orc_extractor *e, double *t6);
+
+/* ---- primitives (unit-testable) -------------------------------------------------- */
+void orc_border_reflect101(const uint8_t *src, int w, int h, int sstride,
+                           uint8_t *dst, int dstride, int border);
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int sstride,
+                          uint8_t *dst, int dw, int dh, int dstride);
+/* cv::FAST(img, kps, threshold, nonmax=true), TYPE_9_16; returns count (may exceed cap) */
+int orc_fast9_16(const uint8_t *img, int w, int h, int stride, int threshold,
+                 orc_keypoint *out, int cap);
+void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride);
+float orc_fast_atan2(float y, float x);
+int orc_cv_round_f(float v);
+/* quadtree on its own: keys in (x,y,response); returns count, writes selected input indices
+ * in output (list) order */
+int orc_distribute_octtree(const orc_keypoint *keys, int nkeys, int minX, int maxX, int minY,
+                           int maxY, int N, int *out_idx, int cap);
+float orc_ic_angle(const uint8_t *img, int stride, int x, int y);
+void orc_descriptor(const uint8_t *blur, int stride, int x, int y, float angle_deg, int fp_mode,
+                    uint8_t *desc32);
+
+/* ---- matcher ------------------------------------------------------------------- */
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b);
+/* brute force: for every query the best (lowest index on ties) / second-best distance */
+void orc_match_bruteforce(const uint8_t *q, int nq, const uint8_t *t, int nt,
+                          int *best_idx, int *best_dist, int *second_dist);
+void orc_three_maxima(const int *hist_sizes, int L, int *ind1, int *ind2, int *ind3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,190 @@
+"""ctypes binding of the CPU oracle (oracle/orb_oracle.h).  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+FP_GCC_FMA, FP_STRICT = 0, 1
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborb_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "orb_oracle_match.c", "orb_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liborb_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        u8p, i32p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int), C.POINTER(C.c_float)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_extract.restype = C.c_int
+        L.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_get_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orc_level_dims.argtypes = [C.c_void_p, C.c_int, i32p, i32p]
+        L.orc_level_image.restype = C.c_void_p
+        L.orc_level_image.argtypes = [C.c_void_p, C.c_int]
+        L.orc_level_blur.restype = C.c_void_p
+        L.orc_level_blur.argtypes = [C.c_void_p, C.c_int]
+        L.orc_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_get_stage_times.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_border_reflect101.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_fast9_16.restype = C.c_int
+        L.orc_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_cv_round_f.restype = C.c_int
+        L.orc_cv_round_f.argtypes = [C.c_float]
+        L.orc_distribute_octtree.restype = C.c_int
+        L.orc_distribute_octtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orc_descriptor_distance.restype = C.c_int
+        L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_match_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_three_maxima.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleExtractor:
+    """CPU oracle of ORBextractor (src/ORBextractor.cc:776-925, 1961-2084)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, fp_mode=FP_GCC_FMA):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.L.orc_create(nfeatures, scale_factor, nlevels, ini_th, min_th, fp_mode)
+        if not self.h:
+            raise ValueError("orc_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        fpl = np.zeros(n, np.int32); umax = np.zeros(16, np.int32)
+        self.L.orc_get_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(fpl), _p(umax))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, features_per_level=fpl, umax=umax)
+
+    def extract(self, img, cap=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        if cap is None:
+            cap = self.nfeatures + 64 * self.nlevels
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        n = self.L.orc_extract(self.h, _p(img), w, h, img.strides[0], _p(kps), _p(desc), cap)
+        if n < 0:
+            return n, None, None
+        return n, kps[:n].copy(), desc[:n].copy()
+
+    def level_image(self, level, blur=False):
+        w, h = C.c_int(), C.c_int()
+        if self.L.orc_level_dims(self.h, level, C.byref(w), C.byref(h)) != 0:
+            return None
+        ptr = (self.L.orc_level_blur if blur else self.L.orc_level_image)(self.h, level)
+        if not ptr:
+            return None
+        buf = (C.c_uint8 * (w.value * h.value)).from_address(ptr)
+        return np.frombuffer(buf, np.uint8).reshape(h.value, w.value).copy()
+
+    def level_candidates(self, level):
+        n = self.L.orc_level_candidates(self.h, level, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.orc_level_candidates(self.h, level, _p(out), n)
+        return out[:n]
+
+    def level_keypoints(self, level):
+        n = self.L.orc_level_keypoints(self.h, level, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.orc_level_keypoints(self.h, level, _p(out), n)
+        return out[:n]
+
+    def stage_times(self):
+        t = np.zeros(6, np.float64)
+        self.L.orc_get_stage_times(self.h, _p(t))
+        return dict(zip(("pyramid", "fast", "quadtree", "orient", "blur", "desc"), t))
+
+
+def fast9_16(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros(w * h, KP_DTYPE)
+    n = lib().orc_fast9_16(_p(img), w, h, img.strides[0], threshold, _p(out), out.size)
+    return out[:n].copy()
+
+
+def resize_linear(img, dw, dh):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(img), w, h, img.strides[0], _p(out), dw, dh, dw)
+    return out
+
+
+def border101(img, border):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+    lib().orc_border_reflect101(_p(img), w, h, img.strides[0], _p(out), out.shape[1], border)
+    return out
+
+
+def gaussian_blur7(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros_like(img)
+    lib().orc_gaussian_blur7(_p(img), w, h, img.strides[0], _p(out), w)
+    return out
+
+
+def distribute_octtree(keys, minX, maxX, minY, maxY, N):
+    keys = np.ascontiguousarray(keys, KP_DTYPE)
+    cap = len(keys) + 16
+    idx = np.zeros(cap, np.int32)
+    n = lib().orc_distribute_octtree(_p(keys), len(keys), minX, maxX, minY, maxY, N, _p(idx), cap)
+    return n, idx[:max(n, 0)].copy()
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def match_bruteforce(q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    nq, nt = len(q), len(t)
+    bi = np.zeros(nq, np.int32); bd = np.zeros(nq, np.int32); sd = np.zeros(nq, np.int32)
+    lib().orc_match_bruteforce(_p(q), nq, _p(t), nt, _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    lib().orc_three_maxima(_p(sizes), len(sizes), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
