@@ -1,0 +1,153 @@
+/* orbx.h -- C ABI of the MI355X-native ORB front-end (liborbx.so).
+ *
+ * The reference (cheukwaylee/ORB_SLAM2_detailed_comments) has no FFI layer: the boundary of
+ * the hot path is the C++ class surface of ORB_SLAM2::ORBextractor (include/ORBextractor.h:82-185)
+ * and ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:54-225).  Every entry point below names the
+ * reference interface it replaces; compat/ORBextractor.h + compat/ORBmatcher.h are the drop-in
+ * C++ classes a maintainer compiles against this ABI.
+ *
+ * Plain pointers and sizes only; no C++/torch/HIP types in any signature.  "device pointer"
+ * arguments are ordinary HIP device addresses (e.g. torch.Tensor.data_ptr()).
+ *
+ * Threading (mirrors src/Frame.cc:158-168): distinct handles are fully concurrent (one HIP
+ * stream + private workspace each); one handle is not re-entrant.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_ABI_VERSION 1
+
+/* Bit-compatible with cv::KeyPoint (28 bytes): what ORBextractor::operator() appends to
+ * std::vector<cv::KeyPoint>& _keypoints (src/ORBextractor.cc:2016-2082). */
+typedef struct orbx_keypoint {
+    float x, y;       /* pt, in level-0 *padded-image* coordinates (fork semantics) */
+    float size;       /* (float)(int)(31 * scale[octave]) */
+    float angle;      /* degrees [0,360) */
+    float response;   /* FAST score */
+    int32_t octave;
+    int32_t class_id; /* always -1 */
+} orbx_keypoint;
+
+typedef enum orbx_status {
+    ORBX_OK = 0,
+    ORBX_EMPTY_IMAGE = 1,   /* reference: silent return, outputs untouched (src/ORBextractor.cc:1966-1967) */
+    ORBX_BAD_ARGUMENT = 2,
+    ORBX_BAD_ASPECT = 3,    /* nIni == 0: reference divides by zero (src/ORBextractor.cc:1059-1063) */
+    ORBX_CAPACITY = 4,      /* caller buffer or internal candidate capacity too small */
+    ORBX_HIP_ERROR = 5,
+    ORBX_NO_DEVICE = 6,
+    ORBX_UNSUPPORTED = 7
+} orbx_status;
+
+enum { ORBX_PYRAMID_FORK_PADDED = 0 };           /* src/ORBextractor.cc:2165-2166 */
+enum { ORBX_FP_GCC_FMA = 0, ORBX_FP_STRICT = 1 }; /* contraction of GET_VALUE, src/ORBextractor.cc:207-209 */
+
+/* The five values ORBextractor's constructor takes (include/ORBextractor.h:104; read from YAML at
+ * src/Tracking.cc:160-168) plus the parity-contract switches and device sizing hints. */
+typedef struct orbx_params {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t pyramid_mode;        /* ORBX_PYRAMID_FORK_PADDED */
+    int32_t fp_mode;             /* ORBX_FP_GCC_FMA (default parity contract) or ORBX_FP_STRICT */
+    int32_t device;              /* HIP device ordinal; -1 = current device */
+    int32_t max_batch;           /* frames in flight per call (>=1) */
+    int32_t max_cand_per_cell;   /* candidate slots per FAST cell, 0 = default (48) */
+} orbx_params;
+
+typedef struct orbx_handle orbx_handle;
+
+/* ---- lifecycle: replaces `new ORBextractor(nFeatures, fScaleFactor, nLevels, fIniThFAST, fMinThFAST)`
+ *      (src/Tracking.cc:171-182) ---------------------------------------------------------- */
+orbx_status orbx_create(const orbx_params *params, orbx_handle **out);
+void orbx_destroy(orbx_handle *h);
+void orbx_default_params(orbx_params *p); /* TUM1.yaml values: 1000, 1.2, 8, 20, 7 */
+const char *orbx_last_error(void);        /* thread-local text of the last failure */
+const char *orbx_status_string(orbx_status s);
+int orbx_abi_version(void);
+
+/* ---- getters: GetLevels / GetScaleFactor(s) / GetInverseScaleFactors / GetScaleSigmaSquares /
+ *      GetInverseScaleSigmaSquares (include/ORBextractor.h:120-170), mnFeaturesPerLevel, umax ---- */
+int orbx_get_levels(const orbx_handle *h);
+float orbx_get_scale_factor(const orbx_handle *h);
+orbx_status orbx_get_scale_tables(const orbx_handle *h, float *scale, float *inv_scale,
+                                  float *sigma2, float *inv_sigma2); /* nlevels floats each, may be NULL */
+orbx_status orbx_get_features_per_level(const orbx_handle *h, int32_t *n_per_level);
+orbx_status orbx_get_umax(const orbx_handle *h, int32_t *umax16);
+/* output capacity that can never overflow: sum over levels of max(N_l + 3, 4 * nIni_l) */
+int orbx_max_keypoints(orbx_handle *h, int width, int height);
+
+/* ---- extraction: replaces ORBextractor::operator()(image, mask, keypoints, descriptors)
+ *      (src/ORBextractor.cc:1961-2084; called from Frame::ExtractORB, src/Frame.cc:468-481) ---- */
+/* one host frame (8-bit gray, `stride` bytes per row); kps[cap], desc[cap*32]; *n = count */
+orbx_status orbx_extract(orbx_handle *h, const uint8_t *img, int width, int height, int stride,
+                         orbx_keypoint *kps, uint8_t *desc, int cap, int *n);
+/* nframes contiguous host frames (frame_stride bytes apart); outputs [nframes][cap] */
+orbx_status orbx_extract_batch(orbx_handle *h, int nframes, const uint8_t *imgs, int width,
+                               int height, int stride, int64_t frame_stride, orbx_keypoint *kps,
+                               uint8_t *desc, int32_t *counts, int cap);
+/* same, all pointers are DEVICE pointers; asynchronous on the handle's stream.  d_status[nframes]
+ * receives a per-frame orbx_status (OK / CAPACITY).  No host synchronisation. */
+orbx_status orbx_extract_batch_device(orbx_handle *h, int nframes, const uint8_t *d_imgs, int width,
+                                      int height, int stride, int64_t frame_stride,
+                                      orbx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts,
+                                      int32_t *d_status, int cap);
+
+/* ---- pyramid access: replaces the public member `mvImagePyramid` (include/ORBextractor.h:185),
+ *      read by Frame::ComputeStereoMatches (src/Frame.cc:910,1040,1072,1079).  Valid until the next
+ *      extract on this handle ("pyramid is overwritten every frame", include/ORBextractor.h:30-35). -- */
+orbx_status orbx_pyramid_level_info(orbx_handle *h, int level, int *width, int *height, int *pitch);
+/* device view of (frame, level): padded image, `pitch` bytes per row */
+orbx_status orbx_pyramid_level_device(orbx_handle *h, int frame, int level, const uint8_t **d_ptr);
+/* copies the padded level into dst (dst_stride >= width) */
+orbx_status orbx_pyramid_level_copy(orbx_handle *h, int frame, int level, uint8_t *dst, int dst_stride);
+
+/* ---- matching: ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2073-2093) evaluated for every
+ *      (query, train) pair with the best / second-best bookkeeping of the search loops
+ *      (e.g. src/ORBmatcher.cc:627-640).  Device pointers, asynchronous on the handle's stream.
+ *      npairs independent problems: pair p uses query rows d_q + p*q_stride (nq[p] rows) and train
+ *      rows d_t + p*t_stride (nt[p] rows); outputs [npairs][out_stride]. ---------------------------- */
+orbx_status orbx_match_bruteforce_device(orbx_handle *h, int npairs, const uint8_t *d_q,
+                                         const int32_t *d_nq, int64_t q_stride, const uint8_t *d_t,
+                                         const int32_t *d_nt, int64_t t_stride, int32_t *d_best_idx,
+                                         int32_t *d_best_dist, int32_t *d_second_dist, int out_stride);
+/* host convenience: one problem, host buffers */
+orbx_status orbx_match_bruteforce(orbx_handle *h, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                                  int32_t *best_idx, int32_t *best_dist, int32_t *second_dist);
+/* full nq x nt distance matrix (uint16), for host-side sequential policies */
+orbx_status orbx_hamming_matrix(orbx_handle *h, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                                uint16_t *dist);
+
+/* ---- stream / timing plumbing ------------------------------------------------------------ */
+void *orbx_get_stream(orbx_handle *h);            /* hipStream_t */
+orbx_status orbx_set_stream(orbx_handle *h, void *hip_stream); /* NULL restores the private stream */
+orbx_status orbx_synchronize(orbx_handle *h);
+/* per-kernel HIP-event timing on the handle's stream.  mask bit k enables kernel id k. */
+enum {
+    ORBX_K_PYR_L0 = 0, ORBX_K_PYR_RESIZE = 1, ORBX_K_FAST = 2, ORBX_K_QUADTREE = 3, ORBX_K_ORIENT = 4,
+    ORBX_K_BLUR = 5, ORBX_K_DESC = 6, ORBX_K_MATCH = 7, ORBX_K_MISC = 8, ORBX_K_COUNT = 9
+};
+orbx_status orbx_profile_enable(orbx_handle *h, uint32_t kernel_mask);
+/* synchronises, then returns accumulated milliseconds and launch counts since the last reset */
+orbx_status orbx_profile_read(orbx_handle *h, float *ms, int32_t *launches, int reset);
+const char *orbx_kernel_name(int kernel_id);
+
+/* ---- per-stage inspection of the last batch (parity tests only; synchronises) -------------- */
+/* candidates of (frame, level) = vToDistributeKeys (src/ORBextractor.cc:1451-1548), border-relative
+ * coordinates, in unspecified order; returns count via *n (may exceed cap => ORBX_CAPACITY) */
+orbx_status orbx_debug_candidates(orbx_handle *h, int frame, int level, orbx_keypoint *out, int cap, int *n);
+/* keypoints of (frame, level) after quadtree + orientation, level coordinates, list order */
+orbx_status orbx_debug_level_keypoints(orbx_handle *h, int frame, int level, orbx_keypoint *out, int cap, int *n);
+/* blurred padded level */
+orbx_status orbx_debug_blur_copy(orbx_handle *h, int frame, int level, uint8_t *dst, int dst_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

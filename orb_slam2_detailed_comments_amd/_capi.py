@@ -1,0 +1,111 @@
+"""ctypes binding of liborbx.so (include/orbx.h).  This is the ONLY way Python reaches the HIP path;
+there is no CPU fallback: a missing library or a missing GPU raises."""
+from __future__ import annotations
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "liborbx.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+OK, EMPTY_IMAGE, BAD_ARGUMENT, BAD_ASPECT, CAPACITY, HIP_ERROR, NO_DEVICE, UNSUPPORTED = range(8)
+FP_GCC_FMA, FP_STRICT = 0, 1
+K_NAMES = ("k_pyr_l0", "k_pyr_resize", "k_fast_cells", "k_quadtree", "k_orient", "k_blur", "k_describe",
+           "k_match", "misc")
+K_COUNT = len(K_NAMES)
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("pyramid_mode", C.c_int32),
+                ("fp_mode", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32),
+                ("max_cand_per_cell", C.c_int32)]
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"orbx status {status}: {msg}")
+        self.status = status
+
+
+# every symbol include/orbx.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "orbx_create", "orbx_destroy", "orbx_default_params", "orbx_last_error", "orbx_status_string",
+    "orbx_abi_version", "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_scale_tables",
+    "orbx_get_features_per_level", "orbx_get_umax", "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch",
+    "orbx_extract_batch_device", "orbx_pyramid_level_info", "orbx_pyramid_level_device",
+    "orbx_pyramid_level_copy", "orbx_match_bruteforce_device", "orbx_match_bruteforce", "orbx_hamming_matrix",
+    "orbx_get_stream", "orbx_set_stream", "orbx_synchronize", "orbx_profile_enable", "orbx_profile_read",
+    "orbx_kernel_name", "orbx_debug_candidates", "orbx_debug_level_keypoints", "orbx_debug_blur_copy",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrbxError(NO_DEVICE, f"{LIB_PATH} is missing: build it with "
+                        "`python -m orb_slam2_detailed_comments_amd.build` (hipcc, gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    L.orbx_create.restype = i32; L.orbx_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.orbx_destroy.restype = None; L.orbx_destroy.argtypes = [vp]
+    L.orbx_default_params.restype = None; L.orbx_default_params.argtypes = [C.POINTER(Params)]
+    L.orbx_last_error.restype = C.c_char_p; L.orbx_last_error.argtypes = []
+    L.orbx_status_string.restype = C.c_char_p; L.orbx_status_string.argtypes = [i32]
+    L.orbx_abi_version.restype = i32
+    L.orbx_get_levels.restype = i32; L.orbx_get_levels.argtypes = [vp]
+    L.orbx_get_scale_factor.restype = f32; L.orbx_get_scale_factor.argtypes = [vp]
+    L.orbx_get_scale_tables.restype = i32; L.orbx_get_scale_tables.argtypes = [vp, vp, vp, vp, vp]
+    L.orbx_get_features_per_level.restype = i32; L.orbx_get_features_per_level.argtypes = [vp, vp]
+    L.orbx_get_umax.restype = i32; L.orbx_get_umax.argtypes = [vp, vp]
+    L.orbx_max_keypoints.restype = i32; L.orbx_max_keypoints.argtypes = [vp, i32, i32]
+    L.orbx_extract.restype = i32; L.orbx_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
+    L.orbx_extract_batch.restype = i32
+    L.orbx_extract_batch.argtypes = [vp, i32, vp, i32, i32, i32, i64, vp, vp, vp, i32]
+    L.orbx_extract_batch_device.restype = i32
+    L.orbx_extract_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, i64, vp, vp, vp, vp, i32]
+    L.orbx_pyramid_level_info.restype = i32
+    L.orbx_pyramid_level_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.orbx_pyramid_level_device.restype = i32; L.orbx_pyramid_level_device.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    L.orbx_pyramid_level_copy.restype = i32; L.orbx_pyramid_level_copy.argtypes = [vp, i32, i32, vp, i32]
+    L.orbx_match_bruteforce_device.restype = i32
+    L.orbx_match_bruteforce_device.argtypes = [vp, i32, vp, vp, i64, vp, vp, i64, vp, vp, vp, i32]
+    L.orbx_match_bruteforce.restype = i32; L.orbx_match_bruteforce.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
+    L.orbx_hamming_matrix.restype = i32; L.orbx_hamming_matrix.argtypes = [vp, vp, i32, vp, i32, vp]
+    L.orbx_get_stream.restype = vp; L.orbx_get_stream.argtypes = [vp]
+    L.orbx_set_stream.restype = i32; L.orbx_set_stream.argtypes = [vp, vp]
+    L.orbx_synchronize.restype = i32; L.orbx_synchronize.argtypes = [vp]
+    L.orbx_profile_enable.restype = i32; L.orbx_profile_enable.argtypes = [vp, C.c_uint32]
+    L.orbx_profile_read.restype = i32; L.orbx_profile_read.argtypes = [vp, vp, vp, i32]
+    L.orbx_kernel_name.restype = C.c_char_p; L.orbx_kernel_name.argtypes = [i32]
+    L.orbx_debug_candidates.restype = i32; L.orbx_debug_candidates.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.orbx_debug_level_keypoints.restype = i32
+    L.orbx_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
+    L.orbx_debug_blur_copy.restype = i32; L.orbx_debug_blur_copy.argtypes = [vp, i32, i32, vp, i32]
+    _lib = L
+    return L
+
+
+def check(status, allow=()):
+    if status != OK and status not in allow:
+        raise OrbxError(status, lib().orbx_last_error().decode(errors="replace"))
+    return status
+
+
+def ptr(a):
+    """numpy array -> void*, torch tensor / int -> device address"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return C.c_void_p(a.data_ptr())

@@ -1,0 +1,583 @@
+// orbx_api.cpp -- the C ABI of liborbx.so (include/orbx.h): handle lifecycle, workspace management,
+// stream / event plumbing and the launch sequence of one batched extraction.
+//
+// Launch sequence per batch (all on one HIP stream, no host synchronisation in the device entry point):
+//   clear counters -> K0 border L0 -> K1 resize x (nlevels-1) -> K2 FAST cells -> K3 quadtree ->
+//   K4 orientation -> K5 blur -> K6 descriptors + assembly.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "orbx_internal.h"
+#include "orbx_launch.h"
+
+static thread_local std::string g_last_error;
+static orbx_status fail(orbx_status s, const std::string &msg) {
+    g_last_error = msg;
+    return s;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(ORBX_HIP_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+struct ProfPair { hipEvent_t a, b; int kid; };
+
+struct orbx_handle {
+    orbx_params p;
+    OrbxTables tab;
+    OrbxGeom geom;
+    DGeom dg;
+    bool host_only = false, configured = false;
+    int dev = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // geometry-dependent device state
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+    OrbxCell *d_cells = nullptr;
+    OrbxTap *d_taps = nullptr;
+    uint2 *d_cand = nullptr;
+    int *d_cand_count = nullptr, *d_lvl_count = nullptr, *d_status = nullptr;
+    uint32_t *d_lvl_kp = nullptr;
+    float *d_lvl_angle = nullptr;
+    uint16_t *d_knode = nullptr;
+    int max_cw = 0, max_ch = 0, ncap = 0, lds_keys = 0;
+    // staging for the host entry points
+    uint8_t *d_in = nullptr; size_t d_in_bytes = 0;
+    orbx_keypoint *d_kps = nullptr; uint8_t *d_desc = nullptr; int *d_counts = nullptr; int *d_ustatus = nullptr;
+    int out_cap = 0;
+    int last_batch = 0;
+    // profiling
+    uint32_t prof_mask = 0;
+    std::vector<ProfPair> pending;
+    std::vector<hipEvent_t> pool;
+    float ms[ORBX_K_COUNT] = {0};
+    int launches[ORBX_K_COUNT] = {0};
+};
+
+static const char *k_names[ORBX_K_COUNT] = {"k_pyr_l0", "k_pyr_resize", "k_fast_cells", "k_quadtree", "k_orient",
+                                            "k_blur",   "k_describe",   "k_match",      "misc"};
+
+extern "C" const char *orbx_kernel_name(int k) { return (k >= 0 && k < ORBX_K_COUNT) ? k_names[k] : "?"; }
+extern "C" const char *orbx_last_error(void) { return g_last_error.c_str(); }
+extern "C" int orbx_abi_version(void) { return ORBX_ABI_VERSION; }
+extern "C" const char *orbx_status_string(orbx_status s) {
+    switch (s) {
+        case ORBX_OK: return "ok";
+        case ORBX_EMPTY_IMAGE: return "empty image";
+        case ORBX_BAD_ARGUMENT: return "bad argument";
+        case ORBX_BAD_ASPECT: return "bad aspect ratio (nIni == 0)";
+        case ORBX_CAPACITY: return "capacity exceeded";
+        case ORBX_HIP_ERROR: return "HIP error";
+        case ORBX_NO_DEVICE: return "no HIP device";
+        case ORBX_UNSUPPORTED: return "unsupported geometry";
+    }
+    return "?";
+}
+
+extern "C" void orbx_default_params(orbx_params *p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->nfeatures = 1000; p->scale_factor = 1.2f; p->nlevels = 8; p->ini_th_fast = 20; p->min_th_fast = 7;
+    p->pyramid_mode = ORBX_PYRAMID_FORK_PADDED; p->fp_mode = ORBX_FP_GCC_FMA;
+    p->device = -1; p->max_batch = 1; p->max_cand_per_cell = 0;
+}
+
+// ---------------------------------------------------------------- profiling helpers
+struct ProfScope {
+    orbx_handle *h; int kid; bool on; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(orbx_handle *h_, int kid_) : h(h_), kid(kid_), on(((h_->prof_mask >> kid_) & 1u) != 0) {
+        if (!on) return;
+        a = grab(); b = grab();
+        hipEventRecord(a, h->stream);
+    }
+    hipEvent_t grab() {
+        if (!h->pool.empty()) { hipEvent_t e = h->pool.back(); h->pool.pop_back(); return e; }
+        hipEvent_t e; hipEventCreate(&e); return e;
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(b, h->stream);
+        h->pending.push_back({a, b, kid});
+    }
+};
+
+static void prof_drain(orbx_handle *h) {
+    if (h->pending.empty()) return;
+    hipStreamSynchronize(h->stream);
+    for (auto &pp : h->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pp.a, pp.b) == hipSuccess) { h->ms[pp.kid] += ms; h->launches[pp.kid]++; }
+        h->pool.push_back(pp.a); h->pool.push_back(pp.b);
+    }
+    h->pending.clear();
+}
+
+// ---------------------------------------------------------------- workspace
+static void free_geometry_buffers(orbx_handle *h) {
+    hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cells); hipFree(h->d_taps); hipFree(h->d_cand);
+    hipFree(h->d_cand_count); hipFree(h->d_lvl_count); hipFree(h->d_status); hipFree(h->d_lvl_kp);
+    hipFree(h->d_lvl_angle); hipFree(h->d_knode);
+    h->d_pyr = h->d_blur = nullptr; h->d_cells = nullptr; h->d_taps = nullptr; h->d_cand = nullptr;
+    h->d_cand_count = h->d_lvl_count = h->d_status = nullptr; h->d_lvl_kp = nullptr; h->d_lvl_angle = nullptr;
+    h->d_knode = nullptr;
+    h->configured = false;
+}
+
+static orbx_status configure(orbx_handle *h, int width, int height) {
+    if (h->configured && h->geom.width == width && h->geom.height == height) return ORBX_OK;
+    if (h->host_only) return fail(ORBX_NO_DEVICE, "host-only handle (device = -2) cannot extract");
+    HIPCHK(hipSetDevice(h->dev));
+    if (h->configured) { HIPCHK(hipStreamSynchronize(h->stream)); free_geometry_buffers(h); }
+    const char *why = "";
+    OrbxGeom g;
+    orbx_status st = orbx_build_geometry(h->p, h->tab, width, height, g, &why);
+    if (st != ORBX_OK) return fail(st, why);
+    h->geom = g;
+    const int B = h->p.max_batch, NL = h->p.nlevels;
+    // device geometry block
+    DGeom &d = h->dg;
+    memset(&d, 0, sizeof(d));
+    d.nlevels = NL; d.ncells = (int)g.cells.size(); d.kp_total = g.kp_total; d.fp_mode = h->p.fp_mode;
+    d.ini_th = std::min(std::max(h->p.ini_th_fast, 0), 255);
+    d.min_th = std::min(std::max(h->p.min_th_fast, 0), 255);
+    d.pyr_bytes = g.pyr_bytes; d.cand_total = g.cand_total;
+    for (int i = 0; i < 16; ++i) d.umax[i] = h->tab.umax[i];
+    int tiles = 0;
+    h->max_cw = h->max_ch = 7;
+    for (const auto &c : g.cells) { h->max_cw = std::max<int>(h->max_cw, c.cw); h->max_ch = std::max<int>(h->max_ch, c.ch); }
+    for (int l = 0; l < NL; ++l) {
+        const OrbxLevelGeom &L = g.lv[l];
+        DLevel &D = d.lv[l];
+        D.pw = L.pw; D.ph = L.ph; D.pitch = L.pitch; D.sw = L.sw; D.sh = L.sh;
+        D.cell_begin = L.cell_begin; D.cell_count = L.cell_count;
+        D.qt_w = L.qt_w; D.qt_h = L.qt_h; D.nini = L.nini; D.hx = L.hx;
+        D.nfeat = L.nfeat; D.kp_cap = L.kp_cap; D.kp_begin = L.kp_begin; D.cand_cap = L.cand_cap;
+        D.tapx = L.tapx_begin; D.tapy = L.tapy_begin; D.scale = L.scale; D.size = L.size;
+        D.off = L.off; D.cand_begin = L.cand_begin;
+        D.blur_tx = (L.pw + 63) / 64;
+        D.blur_tile_begin = tiles;
+        tiles += D.blur_tx * ((L.ph + 15) / 16);
+    }
+    d.blur_tiles = tiles;
+    // quadtree LDS plan: node tables always in LDS, key->node map in LDS when the level's candidates fit
+    h->ncap = g.node_cap;
+    const size_t budget = 100 * 1024;
+    const size_t node_part = orbx_quadtree_smem(h->ncap, 0);
+    if (node_part > 150 * 1024) return fail(ORBX_UNSUPPORTED, "nfeatures too large for the LDS quadtree node table");
+    size_t keys = node_part < budget ? (budget - node_part) / 2 : 0;
+    h->lds_keys = (int)std::min<size_t>(keys, (size_t)g.max_cand_cap);
+    HIPCHK(orbx_quadtree_prepare(orbx_quadtree_smem(h->ncap, h->lds_keys)));
+    // buffers
+    HIPCHK(hipMalloc(&h->d_pyr, (size_t)B * g.pyr_bytes));
+    HIPCHK(hipMalloc(&h->d_blur, (size_t)B * g.pyr_bytes));
+    HIPCHK(hipMalloc(&h->d_cells, std::max<size_t>(1, g.cells.size()) * sizeof(OrbxCell)));
+    HIPCHK(hipMalloc(&h->d_taps, std::max<size_t>(1, g.taps.size()) * sizeof(OrbxTap)));
+    HIPCHK(hipMalloc(&h->d_cand, (size_t)B * g.cand_total * sizeof(uint2)));
+    HIPCHK(hipMalloc(&h->d_knode, (size_t)B * g.cand_total * sizeof(uint16_t)));
+    HIPCHK(hipMalloc(&h->d_cand_count, (size_t)B * NL * sizeof(int)));
+    HIPCHK(hipMalloc(&h->d_lvl_count, (size_t)B * NL * sizeof(int)));
+    HIPCHK(hipMalloc(&h->d_status, (size_t)B * sizeof(int)));
+    HIPCHK(hipMalloc(&h->d_lvl_kp, (size_t)B * g.kp_total * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&h->d_lvl_angle, (size_t)B * g.kp_total * sizeof(float)));
+    if (!g.cells.empty())
+        HIPCHK(hipMemcpy(h->d_cells, g.cells.data(), g.cells.size() * sizeof(OrbxCell), hipMemcpyHostToDevice));
+    if (!g.taps.empty())
+        HIPCHK(hipMemcpy(h->d_taps, g.taps.data(), g.taps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(h->d_pyr, 0, (size_t)B * g.pyr_bytes));
+    HIPCHK(hipMemset(h->d_blur, 0, (size_t)B * g.pyr_bytes));
+    HIPCHK(hipMemset(h->d_lvl_count, 0, (size_t)B * NL * sizeof(int)));
+    HIPCHK(hipMemset(h->d_cand_count, 0, (size_t)B * NL * sizeof(int)));
+    h->configured = true;
+    h->last_batch = 0;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_create(const orbx_params *params, orbx_handle **out) {
+    if (!params || !out) return fail(ORBX_BAD_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (params->nlevels < 1 || params->nlevels > ORBX_MAX_LEVELS) return fail(ORBX_BAD_ARGUMENT, "nlevels out of range [1,16]");
+    if (params->nfeatures < 1 || params->nfeatures > 16000) return fail(ORBX_BAD_ARGUMENT, "nfeatures out of range [1,16000]");
+    if (!(params->scale_factor > 1.0f)) return fail(ORBX_BAD_ARGUMENT, "scale_factor must be > 1");
+    if (params->pyramid_mode != ORBX_PYRAMID_FORK_PADDED) return fail(ORBX_UNSUPPORTED, "only ORBX_PYRAMID_FORK_PADDED is implemented");
+    if (params->fp_mode != ORBX_FP_GCC_FMA && params->fp_mode != ORBX_FP_STRICT) return fail(ORBX_BAD_ARGUMENT, "fp_mode");
+    orbx_handle *h = new orbx_handle();
+    h->p = *params;
+    if (h->p.max_batch < 1) h->p.max_batch = 1;
+    orbx_build_tables(h->p, h->tab);
+    if (params->device == -2) {  // host-only handle: tables and getters, no device work
+        h->host_only = true;
+        *out = h;
+        return ORBX_OK;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        delete h;
+        return fail(ORBX_NO_DEVICE, "no HIP device visible: the ORB front-end has no CPU fallback");
+    }
+    int dev = params->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) { delete h; return fail(ORBX_BAD_ARGUMENT, "device ordinal out of range"); }
+    h->dev = dev;
+    hipError_t e = hipSetDevice(dev);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = orbx_upload_pattern();
+    if (e != hipSuccess) { delete h; return fail(ORBX_HIP_ERROR, hipGetErrorString(e)); }
+    h->stream = h->own_stream;
+    *out = h;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_destroy(orbx_handle *h) {
+    if (!h) return;
+    if (!h->host_only) {
+        hipSetDevice(h->dev);
+        hipStreamSynchronize(h->stream);
+        prof_drain(h);
+        for (auto e : h->pool) hipEventDestroy(e);
+        free_geometry_buffers(h);
+        hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_ustatus);
+        if (h->own_stream) hipStreamDestroy(h->own_stream);
+    }
+    delete h;
+}
+
+// ---------------------------------------------------------------- getters
+extern "C" int orbx_get_levels(const orbx_handle *h) { return h ? h->p.nlevels : 0; }
+extern "C" float orbx_get_scale_factor(const orbx_handle *h) { return h ? (float)(double)h->p.scale_factor : 0.f; }
+extern "C" orbx_status orbx_get_scale_tables(const orbx_handle *h, float *scale, float *inv_scale, float *sigma2,
+                                             float *inv_sigma2) {
+    if (!h) return fail(ORBX_BAD_ARGUMENT, "null handle");
+    const int n = h->p.nlevels;
+    if (scale) memcpy(scale, h->tab.scale, n * sizeof(float));
+    if (inv_scale) memcpy(inv_scale, h->tab.inv_scale, n * sizeof(float));
+    if (sigma2) memcpy(sigma2, h->tab.sigma2, n * sizeof(float));
+    if (inv_sigma2) memcpy(inv_sigma2, h->tab.inv_sigma2, n * sizeof(float));
+    return ORBX_OK;
+}
+extern "C" orbx_status orbx_get_features_per_level(const orbx_handle *h, int32_t *n) {
+    if (!h || !n) return fail(ORBX_BAD_ARGUMENT, "null argument");
+    memcpy(n, h->tab.nfeat, h->p.nlevels * sizeof(int32_t));
+    return ORBX_OK;
+}
+extern "C" orbx_status orbx_get_umax(const orbx_handle *h, int32_t *umax16) {
+    if (!h || !umax16) return fail(ORBX_BAD_ARGUMENT, "null argument");
+    memcpy(umax16, h->tab.umax, 16 * sizeof(int32_t));
+    return ORBX_OK;
+}
+extern "C" int orbx_max_keypoints(orbx_handle *h, int width, int height) {
+    if (!h || width <= 0 || height <= 0) return -1;
+    OrbxGeom g; const char *why = "";
+    if (orbx_build_geometry(h->p, h->tab, width, height, g, &why) != ORBX_OK) { g_last_error = why; return -1; }
+    return g.kp_total;
+}
+
+// ---------------------------------------------------------------- extraction
+static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W, int H, int stride,
+                             int64_t frame_stride, orbx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts,
+                             int32_t *d_status, int cap) {
+    const DGeom &g = h->dg;
+    hipStream_t s = h->stream;
+    const int NL = g.nlevels;
+    { ProfScope ps(h, ORBX_K_MISC);
+      orbx_launch_clear(s, h->d_cand_count, B * NL, h->d_lvl_count, B * NL, d_status, B); }
+    { ProfScope ps(h, ORBX_K_PYR_L0);
+      orbx_launch_pyr_l0(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr); }
+    for (int l = 1; l < NL; ++l) {
+        ProfScope ps(h, ORBX_K_PYR_RESIZE);
+        orbx_launch_pyr_resize(s, g, B, l, h->d_taps, h->d_pyr);
+    }
+    { ProfScope ps(h, ORBX_K_FAST);
+      orbx_launch_fast(s, g, B, h->d_cells, h->d_pyr, h->d_cand, h->d_cand_count, h->max_cw, h->max_ch); }
+    { ProfScope ps(h, ORBX_K_QUADTREE);
+      orbx_launch_quadtree(s, g, B, h->d_cand, h->d_cand_count, h->d_lvl_kp, h->d_lvl_count, d_status, h->d_knode,
+                           h->ncap, h->lds_keys); }
+    { ProfScope ps(h, ORBX_K_ORIENT);
+      orbx_launch_orient(s, g, B, h->d_pyr, h->d_lvl_kp, h->d_lvl_count, h->d_lvl_angle); }
+    { ProfScope ps(h, ORBX_K_BLUR);
+      orbx_launch_blur(s, g, B, h->d_pyr, h->d_blur); }
+    { ProfScope ps(h, ORBX_K_DESC);
+      orbx_launch_describe(s, g, B, h->d_blur, h->d_lvl_kp, h->d_lvl_count, h->d_lvl_angle, d_kps, d_desc, d_counts,
+                           d_status, cap); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ORBX_HIP_ERROR, std::string("kernel launch: ") + hipGetErrorString(e));
+    h->last_batch = B;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_extract_batch_device(orbx_handle *h, int nframes, const uint8_t *d_imgs, int width,
+                                                 int height, int stride, int64_t frame_stride, orbx_keypoint *d_kps,
+                                                 uint8_t *d_desc, int32_t *d_counts, int32_t *d_status, int cap) {
+    if (!h) return fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!d_imgs || width <= 0 || height <= 0 || nframes <= 0) return fail(ORBX_EMPTY_IMAGE, "empty image");
+    if (!d_kps || !d_desc || !d_counts || cap <= 0 || stride < width) return fail(ORBX_BAD_ARGUMENT, "bad output buffers / stride");
+    orbx_status st = configure(h, width, height);
+    if (st != ORBX_OK) return st;
+    HIPCHK(hipSetDevice(h->dev));
+    const int MB = h->p.max_batch;
+    for (int f0 = 0; f0 < nframes; f0 += MB) {
+        const int B = std::min(MB, nframes - f0);
+        int32_t *stp = d_status ? d_status + f0 : h->d_status;
+        st = run_chunk(h, B, d_imgs + (int64_t)f0 * frame_stride, width, height, stride, frame_stride,
+                       d_kps + (int64_t)f0 * cap, d_desc + (int64_t)f0 * cap * 32, d_counts + f0, stp, cap);
+        if (st != ORBX_OK) return st;
+    }
+    return ORBX_OK;
+}
+
+static orbx_status ensure_staging(orbx_handle *h, size_t in_bytes, int cap) {
+    const int MB = h->p.max_batch;
+    if (in_bytes > h->d_in_bytes) {
+        hipFree(h->d_in); h->d_in = nullptr; h->d_in_bytes = 0;
+        HIPCHK(hipMalloc(&h->d_in, in_bytes));
+        h->d_in_bytes = in_bytes;
+    }
+    if (cap > h->out_cap) {
+        hipFree(h->d_kps); hipFree(h->d_desc); h->d_kps = nullptr; h->d_desc = nullptr; h->out_cap = 0;
+        HIPCHK(hipMalloc(&h->d_kps, (size_t)MB * cap * sizeof(orbx_keypoint)));
+        HIPCHK(hipMalloc(&h->d_desc, (size_t)MB * cap * 32));
+        h->out_cap = cap;
+    }
+    if (!h->d_counts) {
+        HIPCHK(hipMalloc(&h->d_counts, (size_t)MB * sizeof(int)));
+        HIPCHK(hipMalloc(&h->d_ustatus, (size_t)MB * sizeof(int)));
+    }
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_extract_batch(orbx_handle *h, int nframes, const uint8_t *imgs, int width, int height,
+                                          int stride, int64_t frame_stride, orbx_keypoint *kps, uint8_t *desc,
+                                          int32_t *counts, int cap) {
+    if (!h) return fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!imgs || width <= 0 || height <= 0 || nframes <= 0) return fail(ORBX_EMPTY_IMAGE, "empty image");
+    if (!kps || !desc || !counts || cap <= 0 || stride < width) return fail(ORBX_BAD_ARGUMENT, "bad output buffers / stride");
+    orbx_status st = configure(h, width, height);
+    if (st != ORBX_OK) return st;
+    HIPCHK(hipSetDevice(h->dev));
+    const int MB = h->p.max_batch;
+    const size_t fbytes = (size_t)stride * height;
+    st = ensure_staging(h, (size_t)MB * fbytes, cap);
+    if (st != ORBX_OK) return st;
+    orbx_status worst = ORBX_OK;
+    std::vector<int> hstat(MB);
+    for (int f0 = 0; f0 < nframes; f0 += MB) {
+        const int B = std::min(MB, nframes - f0);
+        for (int i = 0; i < B; ++i)
+            HIPCHK(hipMemcpyAsync(h->d_in + (size_t)i * fbytes, imgs + (int64_t)(f0 + i) * frame_stride, fbytes,
+                                  hipMemcpyHostToDevice, h->stream));
+        st = run_chunk(h, B, h->d_in, width, height, stride, (int64_t)fbytes, h->d_kps, h->d_desc, h->d_counts,
+                       h->d_ustatus, cap);
+        if (st != ORBX_OK) return st;
+        HIPCHK(hipMemcpyAsync(kps + (int64_t)f0 * cap, h->d_kps, (size_t)B * cap * sizeof(orbx_keypoint),
+                              hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(desc + (int64_t)f0 * cap * 32, h->d_desc, (size_t)B * cap * 32, hipMemcpyDeviceToHost,
+                              h->stream));
+        HIPCHK(hipMemcpyAsync(counts + f0, h->d_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(hstat.data(), h->d_ustatus, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int i = 0; i < B; ++i)
+            if (hstat[i] != ORBX_OK) worst = (orbx_status)hstat[i];
+    }
+    if (worst != ORBX_OK) return fail(worst, "a frame exceeded the keypoint / candidate capacity");
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_extract(orbx_handle *h, const uint8_t *img, int width, int height, int stride,
+                                    orbx_keypoint *kps, uint8_t *desc, int cap, int *n) {
+    if (!n) return fail(ORBX_BAD_ARGUMENT, "null count pointer");
+    int32_t cnt = 0;
+    orbx_status st = orbx_extract_batch(h, 1, img, width, height, stride, (int64_t)stride * height, kps, desc, &cnt, cap);
+    if (st == ORBX_OK || st == ORBX_CAPACITY) *n = cnt;
+    return st;
+}
+
+// ---------------------------------------------------------------- pyramid access
+static orbx_status check_level(orbx_handle *h, int frame, int level) {
+    if (!h) return fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!h->configured || h->last_batch == 0) return fail(ORBX_BAD_ARGUMENT, "no frame extracted yet");
+    if (level < 0 || level >= h->p.nlevels || frame < 0 || frame >= h->last_batch) return fail(ORBX_BAD_ARGUMENT, "frame/level out of range");
+    return ORBX_OK;
+}
+extern "C" orbx_status orbx_pyramid_level_info(orbx_handle *h, int level, int *width, int *height, int *pitch) {
+    orbx_status st = check_level(h, 0, level);
+    if (st != ORBX_OK) return st;
+    if (width) *width = h->geom.lv[level].pw;
+    if (height) *height = h->geom.lv[level].ph;
+    if (pitch) *pitch = h->geom.lv[level].pitch;
+    return ORBX_OK;
+}
+extern "C" orbx_status orbx_pyramid_level_device(orbx_handle *h, int frame, int level, const uint8_t **d_ptr) {
+    orbx_status st = check_level(h, frame, level);
+    if (st != ORBX_OK) return st;
+    *d_ptr = h->d_pyr + (size_t)frame * h->geom.pyr_bytes + h->geom.lv[level].off;
+    return ORBX_OK;
+}
+static orbx_status copy_level(orbx_handle *h, const uint8_t *slab, int frame, int level, uint8_t *dst, int dst_stride) {
+    orbx_status st = check_level(h, frame, level);
+    if (st != ORBX_OK) return st;
+    const OrbxLevelGeom &L = h->geom.lv[level];
+    if (!dst || dst_stride < L.pw) return fail(ORBX_BAD_ARGUMENT, "dst / dst_stride");
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy2D(dst, dst_stride, slab + (size_t)frame * h->geom.pyr_bytes + L.off, L.pitch, L.pw, L.ph,
+                       hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+extern "C" orbx_status orbx_pyramid_level_copy(orbx_handle *h, int frame, int level, uint8_t *dst, int dst_stride) {
+    return copy_level(h, h ? h->d_pyr : nullptr, frame, level, dst, dst_stride);
+}
+extern "C" orbx_status orbx_debug_blur_copy(orbx_handle *h, int frame, int level, uint8_t *dst, int dst_stride) {
+    return copy_level(h, h ? h->d_blur : nullptr, frame, level, dst, dst_stride);
+}
+
+// ---------------------------------------------------------------- per-stage inspection
+extern "C" orbx_status orbx_debug_candidates(orbx_handle *h, int frame, int level, orbx_keypoint *out, int cap, int *n) {
+    orbx_status st = check_level(h, frame, level);
+    if (st != ORBX_OK) return st;
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const OrbxLevelGeom &L = h->geom.lv[level];
+    int cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, h->d_cand_count + frame * h->p.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    if (n) *n = cnt;
+    const int m = std::min(cnt, L.cand_cap);
+    std::vector<uint2> rec(std::max(m, 1));
+    if (m > 0)
+        HIPCHK(hipMemcpy(rec.data(), h->d_cand + (size_t)frame * h->geom.cand_total + L.cand_begin, (size_t)m * sizeof(uint2),
+                         hipMemcpyDeviceToHost));
+    for (int i = 0; i < m && i < cap; ++i) {
+        orbx_keypoint k;
+        k.x = (float)(rec[i].x & 0xfff); k.y = (float)((rec[i].x >> 12) & 0xfff);
+        k.size = 7.f; k.angle = -1.f; k.response = (float)(rec[i].x >> 24);
+        k.octave = 0; k.class_id = (int32_t)(rec[i].y & 0xffffff);  // emission-order key (debug only)
+        out[i] = k;
+    }
+    if (cnt > L.cand_cap || m > cap) return fail(ORBX_CAPACITY, "candidate capacity");
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_debug_level_keypoints(orbx_handle *h, int frame, int level, orbx_keypoint *out, int cap, int *n) {
+    orbx_status st = check_level(h, frame, level);
+    if (st != ORBX_OK) return st;
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const OrbxLevelGeom &L = h->geom.lv[level];
+    int cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, h->d_lvl_count + frame * h->p.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    if (n) *n = cnt;
+    std::vector<uint32_t> pos(std::max(cnt, 1));
+    std::vector<float> ang(std::max(cnt, 1));
+    if (cnt > 0) {
+        HIPCHK(hipMemcpy(pos.data(), h->d_lvl_kp + (size_t)frame * h->geom.kp_total + L.kp_begin, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ang.data(), h->d_lvl_angle + (size_t)frame * h->geom.kp_total + L.kp_begin, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < cnt && i < cap; ++i) {
+        orbx_keypoint k;
+        k.x = (float)((pos[i] & 0xfff) + ORBX_EDGE - 3); k.y = (float)(((pos[i] >> 12) & 0xfff) + ORBX_EDGE - 3);
+        k.size = L.size; k.angle = ang[i]; k.response = (float)(pos[i] >> 24); k.octave = level; k.class_id = -1;
+        out[i] = k;
+    }
+    if (cnt > cap) return fail(ORBX_CAPACITY, "output capacity");
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------- matching
+extern "C" orbx_status orbx_match_bruteforce_device(orbx_handle *h, int npairs, const uint8_t *d_q, const int32_t *d_nq,
+                                                    int64_t q_stride, const uint8_t *d_t, const int32_t *d_nt,
+                                                    int64_t t_stride, int32_t *d_best_idx, int32_t *d_best_dist,
+                                                    int32_t *d_second_dist, int out_stride) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (npairs <= 0 || !d_q || !d_t || !d_nq || !d_nt || !d_best_idx || !d_best_dist || !d_second_dist || out_stride <= 0)
+        return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    HIPCHK(hipSetDevice(h->dev));
+    { ProfScope ps(h, ORBX_K_MATCH);
+      orbx_launch_match(h->stream, npairs, out_stride, d_q, d_nq, q_stride, d_t, d_nt, t_stride, d_best_idx, d_best_dist,
+                        d_second_dist, out_stride); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_match_bruteforce(orbx_handle *h, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                                             int32_t *best_idx, int32_t *best_dist, int32_t *second_dist) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (nq < 0 || nt < 0 || (nq > 0 && (!q || !best_idx || !best_dist || !second_dist)) || (nt > 0 && !t))
+        return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    if (nq == 0) return ORBX_OK;
+    HIPCHK(hipSetDevice(h->dev));
+    uint8_t *dq = nullptr, *dt = nullptr; int *dn = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc(&dq, (size_t)nq * 32));
+    HIPCHK(hipMalloc(&dt, (size_t)std::max(nt, 1) * 32));
+    HIPCHK(hipMalloc(&dn, 2 * sizeof(int)));
+    HIPCHK(hipMalloc(&dout, (size_t)3 * nq * sizeof(int)));
+    int hn[2] = {nq, nt};
+    HIPCHK(hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice));
+    if (nt > 0) HIPCHK(hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dn, hn, sizeof(hn), hipMemcpyHostToDevice));
+    orbx_status st = orbx_match_bruteforce_device(h, 1, dq, dn, 0, dt, dn + 1, 0, dout, dout + nq, dout + 2 * nq, nq);
+    if (st == ORBX_OK) {
+        hipStreamSynchronize(h->stream);
+        hipMemcpy(best_idx, dout, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
+        hipMemcpy(best_dist, dout + nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
+        hipMemcpy(second_dist, dout + 2 * nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
+    }
+    hipFree(dq); hipFree(dt); hipFree(dn); hipFree(dout);
+    return st;
+}
+
+extern "C" orbx_status orbx_hamming_matrix(orbx_handle *h, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                                           uint16_t *dist) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (nq <= 0 || nt <= 0) return ORBX_OK;
+    if (!q || !t || !dist) return fail(ORBX_BAD_ARGUMENT, "null argument");
+    HIPCHK(hipSetDevice(h->dev));
+    uint8_t *dq = nullptr, *dt = nullptr; uint16_t *dd = nullptr;
+    HIPCHK(hipMalloc(&dq, (size_t)nq * 32));
+    HIPCHK(hipMalloc(&dt, (size_t)nt * 32));
+    HIPCHK(hipMalloc(&dd, (size_t)nq * nt * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice));
+    { ProfScope ps(h, ORBX_K_MATCH);
+      orbx_launch_hamming_matrix(h->stream, dq, nq, dt, nt, dd); }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(dist, dd, (size_t)nq * nt * sizeof(uint16_t), hipMemcpyDeviceToHost);
+    hipFree(dq); hipFree(dt); hipFree(dd);
+    if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------- stream / timing
+extern "C" void *orbx_get_stream(orbx_handle *h) { return h ? (void *)h->stream : nullptr; }
+extern "C" orbx_status orbx_set_stream(orbx_handle *h, void *s) {
+    if (!h || h->host_only) return fail(ORBX_BAD_ARGUMENT, "no device handle");
+    hipSetDevice(h->dev);
+    hipStreamSynchronize(h->stream);
+    prof_drain(h);
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return ORBX_OK;
+}
+extern "C" orbx_status orbx_synchronize(orbx_handle *h) {
+    if (!h || h->host_only) return fail(ORBX_BAD_ARGUMENT, "no device handle");
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ORBX_OK;
+}
+extern "C" orbx_status orbx_profile_enable(orbx_handle *h, uint32_t mask) {
+    if (!h || h->host_only) return fail(ORBX_BAD_ARGUMENT, "no device handle");
+    prof_drain(h);
+    h->prof_mask = mask;
+    return ORBX_OK;
+}
+extern "C" orbx_status orbx_profile_read(orbx_handle *h, float *ms, int32_t *launches, int reset) {
+    if (!h || h->host_only) return fail(ORBX_BAD_ARGUMENT, "no device handle");
+    hipSetDevice(h->dev);
+    prof_drain(h);
+    if (ms) memcpy(ms, h->ms, sizeof(h->ms));
+    if (launches) memcpy(launches, h->launches, sizeof(h->launches));
+    if (reset) { memset(h->ms, 0, sizeof(h->ms)); memset(h->launches, 0, sizeof(h->launches)); }
+    return ORBX_OK;
+}

@@ -1,0 +1,67 @@
+// orbx_device.h -- device-side geometry block passed BY VALUE to every kernel (lives in the kernarg
+// segment -> scalar loads), plus small device helpers shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "orbx_internal.h"
+#include "orbx_sincos.h"
+
+struct DLevel {
+    int pw, ph, pitch, sw, sh;
+    int cell_begin, cell_count;
+    int qt_w, qt_h, nini;
+    float hx;
+    int nfeat, kp_cap, kp_begin, cand_cap;
+    int tapx, tapy;
+    float scale, size;
+    int blur_tile_begin, blur_tx;  // flattened blur tile table
+    long long off;                 // byte offset in the per-frame pyramid slab
+    long long cand_begin;          // record offset in the per-frame candidate table
+};
+
+struct DGeom {
+    int nlevels, ncells, kp_total, fp_mode;
+    int ini_th, min_th, blur_tiles, pad0;
+    long long pyr_bytes, cand_total;
+    int umax[16];
+    DLevel lv[ORBX_MAX_LEVELS];
+};
+
+#define ORBX_WAVE 64
+
+__device__ __forceinline__ int orbx_reflect101(int i, int n) {
+    // single reflection is enough for |overshoot| < n (borders here are <= 19 px, n >= 20 enforced on host;
+    // the loop keeps it exact for any n > 1)
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+__device__ __forceinline__ int orbx_wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// cv::fastAtan2 (degrees), OpenCV 3.2 atanImpl<float>; no contraction (file is built -ffp-contract=off)
+__device__ __forceinline__ float orbx_fast_atan2(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+

@@ -1,0 +1,27 @@
+// orbx_launch.h -- kernel launch wrappers (defined in orbx_kernels.hip, used by orbx_api.cpp)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "orbx_device.h"
+
+hipError_t orbx_upload_pattern();
+size_t orbx_quadtree_smem(int ncap, int lds_keys);
+hipError_t orbx_quadtree_prepare(size_t smem);
+void orbx_launch_clear(hipStream_t s, int *a, int na, int *b, int nb, int *c, int nc);
+void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
+                        long long frame_stride, uint8_t *pyr);
+void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr);
+void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint8_t *pyr, uint2 *cand,
+                      int *cand_count, int max_cw, int max_ch);
+void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const uint2 *cand, const int *cand_count,
+                          uint32_t *lvl_kp, int *lvl_count, int *status, uint16_t *knode_glob, int ncap,
+                          int lds_keys);
+void orbx_launch_orient(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
+                        const int *lvl_count, float *lvl_angle);
+void orbx_launch_blur(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, uint8_t *blur);
+void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *blur, const uint32_t *lvl_kp,
+                          const int *lvl_count, const float *lvl_angle, orbx_keypoint *kps, uint8_t *desc,
+                          int *counts, int *status, int cap);
+void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,
+                       const uint8_t *t, const int *nt, long long t_stride, int *best_idx, int *best_dist,
+                       int *second_dist, int out_stride);
+void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *dist);

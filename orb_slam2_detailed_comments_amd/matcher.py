@@ -1,0 +1,69 @@
+"""Host-side mirror of ORB_SLAM2::ORBmatcher (reference include/ORBmatcher.h:54-225) over the C ABI.
+
+The Hamming distances come from the HIP kernels; the order-dependent bookkeeping of each policy stays on the
+host exactly as SURVEY.md Appendix E prescribes.
+"""
+from __future__ import annotations
+import numpy as np
+from . import _capi
+from ._capi import check, ptr, lib
+
+
+class ORBmatcher:
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # src/ORBmatcher.cc:49-51
+
+    def __init__(self, nnratio=0.6, checkOri=True, *, extractor=None, device=-1):
+        from .extractor import ORBextractor
+        self.mfNNratio = np.float32(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self._own = extractor is None
+        self._ex = extractor if extractor is not None else ORBextractor(device=device)
+        self._L = lib()
+
+    # ---- DescriptorDistance (src/ORBmatcher.cc:2073-2093), batched: full matrix on the GPU
+    def distance_matrix(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+        out = np.zeros((len(q), len(t)), np.uint16)
+        if len(q) and len(t):
+            check(self._L.orbx_hamming_matrix(self._ex.handle, ptr(q), len(q), ptr(t), len(t), ptr(out)))
+        return out
+
+    def DescriptorDistance(self, a, b):
+        return int(self.distance_matrix(np.asarray(a).reshape(1, 32), np.asarray(b).reshape(1, 32))[0, 0])
+
+    # ---- brute-force best / second best (the superset primitive named in SURVEY section 8d)
+    def match_bruteforce(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+        nq, nt = len(q), len(t)
+        bi = np.full(nq, -1, np.int32); bd = np.full(nq, 0x7fffffff, np.int32); sd = np.full(nq, 0x7fffffff, np.int32)
+        if nq:
+            check(self._L.orbx_match_bruteforce(self._ex.handle, ptr(q), nq, ptr(t), nt, ptr(bi), ptr(bd), ptr(sd)))
+        return bi, bd, sd
+
+    def match_ratio(self, q, t, th=None):
+        """best <= th and best < ratio * second  ->  train index, else -1"""
+        bi, bd, sd = self.match_bruteforce(q, t)
+        th = self.TH_LOW if th is None else th
+        ok = (bd <= th) & (bd.astype(np.float32) < sd.astype(np.float32) * self.mfNNratio)
+        return np.where(ok, bi, -1).astype(np.int32)
+
+    # ---- ComputeThreeMaxima (src/ORBmatcher.cc:2026-2068): 30 numbers, host side
+    @staticmethod
+    def ComputeThreeMaxima(sizes):
+        max1 = max2 = max3 = 0
+        ind1 = ind2 = ind3 = -1
+        for i, s in enumerate(sizes):
+            s = int(s)
+            if s > max1:
+                max3, max2, max1 = max2, max1, s
+                ind3, ind2, ind1 = ind2, ind1, i
+            elif s > max2:
+                max3, max2 = max2, s
+                ind3, ind2 = ind2, i
+            elif s > max3:
+                max3, ind3 = s, i
+        if max2 < np.float32(0.1) * np.float32(max1):
+            ind2 = ind3 = -1
+        elif max3 < np.float32(0.1) * np.float32(max1):
+            ind3 = -1
+        return ind1, ind2, ind3
