@@ -1,0 +1,86 @@
+"""Batched-frames mode across the GPUs of one node.
+
+Frames are independent units (the extractor keeps no cross-frame state, reference include/ORBextractor.h:30-35),
+so a batch is cut into contiguous blocks, one block per rank, with NO collective on the data path.  The only
+exchange is the gather of the per-frame result records -- one fixed-stride all-gather per batch:
+
+    record(frame) = { int32 count ; orbx_keypoint[cap] ; uint8 desc[cap][32] }
+
+`torch.distributed` backend "nccl" is RCCL on ROCm (xGMI between the 8 GPUs); "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+import torch
+import torch.distributed as dist
+
+KP_BYTES = 28
+DESC_BYTES = 32
+
+
+def shard_range(nframes: int, world: int, rank: int):
+    """contiguous block [begin, end) of rank `rank`; blocks differ by at most one frame"""
+    base, rem = divmod(nframes, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def record_bytes(cap: int) -> int:
+    return 4 + cap * (KP_BYTES + DESC_BYTES)
+
+
+def pack_records(counts: torch.Tensor, kps: torch.Tensor, desc: torch.Tensor, out: torch.Tensor = None):
+    """counts int32[B], kps uint8[B, cap*28] (raw keypoint bytes), desc uint8[B, cap*32] -> uint8[B, record_bytes]"""
+    b = counts.shape[0]
+    cap = desc.shape[1] // DESC_BYTES
+    rb = record_bytes(cap)
+    if out is None:
+        out = torch.empty((b, rb), dtype=torch.uint8, device=counts.device)
+    out[:, 0:4] = counts.view(torch.uint8).view(b, 4)
+    out[:, 4:4 + cap * KP_BYTES] = kps
+    out[:, 4 + cap * KP_BYTES:] = desc
+    return out
+
+
+def unpack_records(buf: torch.Tensor, cap: int):
+    b = buf.shape[0]
+    counts = buf[:, 0:4].contiguous().view(torch.int32).view(b)
+    kps = buf[:, 4:4 + cap * KP_BYTES]
+    desc = buf[:, 4 + cap * KP_BYTES:]
+    return counts, kps, desc
+
+
+class RecordGatherer:
+    """One all-gather of equal-sized per-rank record blocks per batch, optionally left in flight
+    (async) while the next batch is computed."""
+
+    def __init__(self, frames_per_rank: int, cap: int, device, group=None):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.group = group
+        self.cap = cap
+        self.rb = record_bytes(cap)
+        self.frames_per_rank = frames_per_rank
+        self.send = [torch.empty((frames_per_rank, self.rb), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = [torch.empty((self.world * frames_per_rank, self.rb), dtype=torch.uint8, device=device)
+                     for _ in range(2)]
+        self.work = [None, None]
+        self.slot = 0
+
+    def gather(self, counts, kps, desc, async_op=False):
+        s = self.slot
+        if self.work[s] is not None:
+            self.work[s].wait()
+            self.work[s] = None
+        pack_records(counts, kps, desc, out=self.send[s])
+        if self.world == 1:
+            self.recv[s].copy_(self.send[s])
+            w = None
+        else:
+            w = dist.all_gather_into_tensor(self.recv[s], self.send[s], group=self.group, async_op=async_op)
+        self.work[s] = w if async_op else None
+        self.slot ^= 1
+        return self.recv[s]
+
+    def wait_all(self):
+        for i in (0, 1):
+            if self.work[i] is not None:
+                self.work[i].wait()
+                self.work[i] = None
