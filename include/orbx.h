@@ -58,7 +58,7 @@ typedef struct orbx_params {
     int32_t fp_mode;             /* ORBX_FP_GCC_FMA (default parity contract) or ORBX_FP_STRICT */
     int32_t device;              /* HIP device ordinal; -1 = current device */
     int32_t max_batch;           /* frames in flight per call (>=1) */
-    int32_t max_cand_per_cell;   /* candidate slots per FAST cell, 0 = default (48) */
+    int32_t max_cand_per_cell;   /* candidate slots per FAST cell; 0 = exact worst case (never overflows) */
 } orbx_params;
 
 typedef struct orbx_handle orbx_handle;
@@ -80,7 +80,8 @@ orbx_status orbx_get_scale_tables(const orbx_handle *h, float *scale, float *inv
                                   float *sigma2, float *inv_sigma2); /* nlevels floats each, may be NULL */
 orbx_status orbx_get_features_per_level(const orbx_handle *h, int32_t *n_per_level);
 orbx_status orbx_get_umax(const orbx_handle *h, int32_t *umax16);
-/* output capacity that can never overflow: sum over levels of max(N_l + 3, 4 * nIni_l) */
+/* output capacity that can never overflow: sum over levels of max(N_l + 3, 4 * nIni_l);
+ * < 0: -(orbx_status) (e.g. -ORBX_BAD_ASPECT) */
 int orbx_max_keypoints(orbx_handle *h, int width, int height);
 
 /* ---- extraction: replaces ORBextractor::operator()(image, mask, keypoints, descriptors)

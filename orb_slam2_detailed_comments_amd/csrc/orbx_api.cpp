@@ -270,9 +270,10 @@ extern "C" orbx_status orbx_get_umax(const orbx_handle *h, int32_t *umax16) {
     return ORBX_OK;
 }
 extern "C" int orbx_max_keypoints(orbx_handle *h, int width, int height) {
-    if (!h || width <= 0 || height <= 0) return -1;
+    if (!h || width <= 0 || height <= 0) return -(int)ORBX_BAD_ARGUMENT;
     OrbxGeom g; const char *why = "";
-    if (orbx_build_geometry(h->p, h->tab, width, height, g, &why) != ORBX_OK) { g_last_error = why; return -1; }
+    const orbx_status st = orbx_build_geometry(h->p, h->tab, width, height, g, &why);
+    if (st != ORBX_OK) { g_last_error = why; return -(int)st; }
     return g.kp_total;
 }
 

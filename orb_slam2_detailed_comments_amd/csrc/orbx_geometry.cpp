@@ -86,7 +86,6 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
                                 const char **why) {
     g = OrbxGeom();
     g.width = width; g.height = height; g.nlevels = p.nlevels;
-    const int cpc = p.max_cand_per_cell > 0 ? p.max_cand_per_cell : 48;
     int64_t off = 0, cand_off = 0;
     int kp_off = 0;
     for (int l = 0; l < p.nlevels; ++l) {
@@ -110,11 +109,13 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
         L.ncols = (int)(fw / 30.f);
         L.nrows = (int)(fh / 30.f);
         L.cell_begin = (int)g.cells.size();
+        int nms_bound = 0;
         L.wcell = L.hcell = 0;
         if (L.ncols > 0 && L.nrows > 0) {
             L.wcell = (int)std::ceil(fw / L.ncols);
             L.hcell = (int)std::ceil(fh / L.nrows);
-            if (L.wcell + 6 > 63 || L.hcell + 6 > 63) { *why = "cell larger than 63 px"; return ORBX_UNSUPPORTED; }
+            // local keypoint coordinates are < cell size - 3 and must fit 6 bits of the emission-order key; wCell < 60 always
+            if (L.wcell + 6 > 67 || L.hcell + 6 > 67) { *why = "cell larger than 67 px"; return ORBX_UNSUPPORTED; }
             int ord = 0;
             for (int i = 0; i < L.nrows; ++i) {
                 const float iniY = (float)(minB + i * L.hcell);
@@ -132,7 +133,11 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
                     c.offx = (int16_t)(j * L.wcell); c.offy = (int16_t)(i * L.hcell);
                     c.level = (int16_t)l;
                     c.idx_in_level = (int16_t)ord++;
-                    if (c.cw >= 7 && c.ch >= 7) g.cells.push_back(c);  // cv::FAST yields nothing below 7x7
+                    if (c.cw >= 7 && c.ch >= 7) {  // cv::FAST yields nothing below 7x7
+                        g.cells.push_back(c);
+                        // strict 3x3 maxima: at most one survivor per 2x2 block of the cell interior
+                        nms_bound += ((c.cw - 6 + 1) / 2) * ((c.ch - 6 + 1) / 2);
+                    }
                 }
             }
             if (ord > 4095) { *why = "more than 4095 FAST cells in one level"; return ORBX_UNSUPPORTED; }
@@ -148,7 +153,8 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
         L.kp_cap = std::max(L.nfeat + 3, 4 * L.nini);
         L.kp_begin = kp_off;
         kp_off += L.kp_cap;
-        L.cand_cap = std::max(64, L.cell_count * cpc);
+        // default: the exact worst case (cannot overflow); max_cand_per_cell > 0 trades memory for an ORBX_CAPACITY risk
+        L.cand_cap = std::max(64, p.max_cand_per_cell > 0 ? std::min(nms_bound, L.cell_count * p.max_cand_per_cell) : nms_bound);
         L.cand_begin = cand_off;
         cand_off += L.cand_cap;
         g.node_cap = std::max(g.node_cap, L.kp_cap + 8);

@@ -81,7 +81,7 @@ __device__ __forceinline__ bool orbx_arc9(uint32_t mask16) {
     return (a & 0xffffu) != 0;
 }
 
-// dynamic LDS: tile[rows*TP] | score[rows*TP] | list u16[lcap] | surv u32[lcap/4+1]; TP = tile pitch (bytes, %4==0)
+// dynamic LDS: tile[rows*TP] | score[rows*TP] | list u16[lcap] | surv u32[scap]; TP = tile pitch (bytes, %4==0)
 __global__ __launch_bounds__(64) void k_fast_cells(DGeom g, const OrbxCell *__restrict__ cells,
                                                    const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
                                                    int *__restrict__ cand_count, int FAST_TP, int rows, int lcap) {
@@ -773,7 +773,8 @@ void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cell
     if (g.ncells == 0) return;
     const int tp = (max_cw + 3 + 3) & ~3;           // +3: dword-alignment shift of the tile origin
     const int lcap = (max_cw - 6) * (max_ch - 6);   // every interior pixel could be a corner
-    const size_t smem = (size_t)2 * max_ch * tp + ((2 * lcap + 3) & ~3) + 4 * (size_t)(lcap / 4 + 1);
+    const int scap = ((max_cw - 6 + 1) / 2) * ((max_ch - 6 + 1) / 2);  // strict 3x3 maxima: <= 1 per 2x2 block
+    const size_t smem = (size_t)2 * max_ch * tp + ((2 * lcap + 3) & ~3) + 4 * (size_t)scap;
     hipLaunchKernelGGL(k_fast_cells, dim3(g.ncells, B), dim3(64), smem, s, g, cells, pyr, cand, cand_count, tp,
                        max_ch, lcap);
 }

@@ -75,7 +75,7 @@ class ORBextractor:
     def max_keypoints(self, width, height):
         n = self._L.orbx_max_keypoints(self._h, width, height)
         if n < 0:
-            raise _capi.OrbxError(_capi.UNSUPPORTED, self._L.orbx_last_error().decode())
+            raise _capi.OrbxError(-n, self._L.orbx_last_error().decode())
         return n
 
     # ---- operator()

@@ -24,10 +24,8 @@ def distribute(xs, ys, resp, order, qt_w, qt_h, N):
     """xs, ys: int coords relative to the border; resp: scores; order: emission-order keys (unique).
     Returns the selected key indices in list order."""
     K = len(xs)
-    nini = int(np.float32(qt_w) / np.float32(qt_h) + np.float32(0.5)) if qt_w / qt_h >= 0 else 0
-    nini = int(np.round(np.float32(qt_w) / np.float32(qt_h)))  # roundf: halves away from zero (positive here)
-    if np.float32(qt_w) / np.float32(qt_h) - np.floor(np.float32(qt_w) / np.float32(qt_h)) == 0.5:
-        nini = int(np.floor(np.float32(qt_w) / np.float32(qt_h))) + 1
+    ratio = np.float32(qt_w) / np.float32(qt_h)
+    nini = int(np.floor(np.float64(ratio) + 0.5))  # C round(): halves away from zero (ratio > 0)
     hx = np.float32(qt_w) / np.float32(nini)
     knode = np.zeros(K, np.int64)
     rootcnt = np.zeros(nini, np.int64)

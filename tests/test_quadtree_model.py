@@ -62,8 +62,8 @@ def test_quadtree_invariants(seed, N):
     assert 0 <= n <= max(N + 3, 4 * nini)          # the quota can be overshot by at most 3
     assert n <= len(pts)
     assert len(set(idx.tolist())) == n              # one keypoint per node, no duplicates
-    if len(pts) <= N:                               # enough budget: every distinct point survives
-        assert n == len(pts) or n >= N
+    # note: n may stay below min(N, #points): a pass that only moves a 2-key node into one child leaves the
+    # list size unchanged and the reference stops there (lNodes.size() == prevSize, :1260-1268)
 
 
 def test_bad_aspect_is_reported():
