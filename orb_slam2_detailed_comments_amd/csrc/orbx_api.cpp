@@ -40,7 +40,8 @@ struct orbx_handle {
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     OrbxCell *d_cells = nullptr;
     OrbxTap *d_taps = nullptr;
-    uint2 *d_cand = nullptr;
+    uint2 *d_cand = nullptr, *d_dense = nullptr;   // per-cell candidate slots / dense per-level key arrays
+    int *d_cell_count = nullptr;
     int *d_cand_count = nullptr, *d_lvl_count = nullptr, *d_status = nullptr;
     uint32_t *d_lvl_kp = nullptr;
     float *d_lvl_angle = nullptr;
@@ -120,6 +121,7 @@ static void prof_drain(orbx_handle *h) {
 // ---------------------------------------------------------------- workspace
 static void free_geometry_buffers(orbx_handle *h) {
     hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cells); hipFree(h->d_taps); hipFree(h->d_cand);
+    hipFree(h->d_dense); hipFree(h->d_cell_count); h->d_dense = nullptr; h->d_cell_count = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_lvl_count); hipFree(h->d_status); hipFree(h->d_lvl_kp);
     hipFree(h->d_lvl_angle); hipFree(h->d_knode);
     h->d_pyr = h->d_blur = nullptr; h->d_cells = nullptr; h->d_taps = nullptr; h->d_cand = nullptr;
@@ -159,25 +161,27 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
         D.nfeat = L.nfeat; D.kp_cap = L.kp_cap; D.kp_begin = L.kp_begin; D.cand_cap = L.cand_cap;
         D.tapx = L.tapx_begin; D.tapy = L.tapy_begin; D.scale = L.scale; D.size = L.size;
         D.off = L.off; D.cand_begin = L.cand_begin;
-        D.blur_tx = (L.pw + 63) / 64;
+        D.blur_tx = (L.pw + 127) / 128;  // k_blur tile = 128 x 32
         D.blur_tile_begin = tiles;
-        tiles += D.blur_tx * ((L.ph + 15) / 16);
+        tiles += D.blur_tx * ((L.ph + 31) / 32);
     }
     d.blur_tiles = tiles;
     // quadtree LDS plan: node tables always in LDS, key->node map in LDS when the level's candidates fit
     h->ncap = g.node_cap;
-    const size_t budget = 100 * 1024;
+    // keys of a level live in LDS when they fit 12288 slots (24 KB): keeps >= 2 quadtree workgroups per CU;
+    // denser levels fall back to the global scratch map (same code path through a generic pointer)
     const size_t node_part = orbx_quadtree_smem(h->ncap, 0);
-    if (node_part > 150 * 1024) return fail(ORBX_UNSUPPORTED, "nfeatures too large for the LDS quadtree node table");
-    size_t keys = node_part < budget ? (budget - node_part) / 2 : 0;
-    h->lds_keys = (int)std::min<size_t>(keys, (size_t)g.max_cand_cap);
+    if (node_part > 120 * 1024) return fail(ORBX_UNSUPPORTED, "nfeatures too large for the LDS quadtree node table");
+    h->lds_keys = (int)std::min<size_t>(12288, (size_t)g.max_cand_cap);
     HIPCHK(orbx_quadtree_prepare(orbx_quadtree_smem(h->ncap, h->lds_keys)));
     // buffers
-    HIPCHK(hipMalloc(&h->d_pyr, (size_t)B * g.pyr_bytes));
-    HIPCHK(hipMalloc(&h->d_blur, (size_t)B * g.pyr_bytes));
+    HIPCHK(hipMalloc(&h->d_pyr, (size_t)B * g.pyr_bytes + 256));   // +256: kernels read whole aligned dwords
+    HIPCHK(hipMalloc(&h->d_blur, (size_t)B * g.pyr_bytes + 256));
     HIPCHK(hipMalloc(&h->d_cells, std::max<size_t>(1, g.cells.size()) * sizeof(OrbxCell)));
     HIPCHK(hipMalloc(&h->d_taps, std::max<size_t>(1, g.taps.size()) * sizeof(OrbxTap)));
     HIPCHK(hipMalloc(&h->d_cand, (size_t)B * g.cand_total * sizeof(uint2)));
+    HIPCHK(hipMalloc(&h->d_dense, (size_t)B * g.cand_total * sizeof(uint2)));
+    HIPCHK(hipMalloc(&h->d_cell_count, (size_t)B * std::max<size_t>(1, g.cells.size()) * sizeof(int)));
     HIPCHK(hipMalloc(&h->d_knode, (size_t)B * g.cand_total * sizeof(uint16_t)));
     HIPCHK(hipMalloc(&h->d_cand_count, (size_t)B * NL * sizeof(int)));
     HIPCHK(hipMalloc(&h->d_lvl_count, (size_t)B * NL * sizeof(int)));
@@ -293,9 +297,10 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
         orbx_launch_pyr_resize(s, g, B, l, h->d_taps, h->d_pyr);
     }
     { ProfScope ps(h, ORBX_K_FAST);
-      orbx_launch_fast(s, g, B, h->d_cells, h->d_pyr, h->d_cand, h->d_cand_count, h->max_cw, h->max_ch); }
+      orbx_launch_fast(s, g, B, h->d_cells, h->d_pyr, h->d_cand, h->d_cell_count, h->max_cw, h->max_ch); }
     { ProfScope ps(h, ORBX_K_QUADTREE);
-      orbx_launch_quadtree(s, g, B, h->d_cand, h->d_cand_count, h->d_lvl_kp, h->d_lvl_count, d_status, h->d_knode,
+      orbx_launch_quadtree(s, g, B, h->d_cells, h->d_cand, h->d_cell_count, h->d_dense, h->d_cand_count, h->d_lvl_kp,
+                           h->d_lvl_count, d_status, h->d_knode,
                            h->ncap, h->lds_keys); }
     { ProfScope ps(h, ORBX_K_ORIENT);
       orbx_launch_orient(s, g, B, h->d_pyr, h->d_lvl_kp, h->d_lvl_count, h->d_lvl_angle); }
@@ -448,7 +453,7 @@ extern "C" orbx_status orbx_debug_candidates(orbx_handle *h, int frame, int leve
     const int m = std::min(cnt, L.cand_cap);
     std::vector<uint2> rec(std::max(m, 1));
     if (m > 0)
-        HIPCHK(hipMemcpy(rec.data(), h->d_cand + (size_t)frame * h->geom.cand_total + L.cand_begin, (size_t)m * sizeof(uint2),
+        HIPCHK(hipMemcpy(rec.data(), h->d_dense + (size_t)frame * h->geom.cand_total + L.cand_begin, (size_t)m * sizeof(uint2),
                          hipMemcpyDeviceToHost));
     for (int i = 0; i < m && i < cap; ++i) {
         orbx_keypoint k;

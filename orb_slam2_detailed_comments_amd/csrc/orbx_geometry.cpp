@@ -134,9 +134,14 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
                     c.level = (int16_t)l;
                     c.idx_in_level = (int16_t)ord++;
                     if (c.cw >= 7 && c.ch >= 7) {  // cv::FAST yields nothing below 7x7
+                        // strict 3x3 maxima: at most one survivor per 2x2 block of the cell interior.  Default = that
+                        // exact worst case (cannot overflow); max_cand_per_cell > 0 trades memory for an ORBX_CAPACITY risk
+                        int bound = ((c.cw - 6 + 1) / 2) * ((c.ch - 6 + 1) / 2);
+                        if (p.max_cand_per_cell > 0) bound = std::min(bound, p.max_cand_per_cell);
+                        c.slot_begin = nms_bound;
+                        c.slot_cap = bound;
+                        nms_bound += bound;
                         g.cells.push_back(c);
-                        // strict 3x3 maxima: at most one survivor per 2x2 block of the cell interior
-                        nms_bound += ((c.cw - 6 + 1) / 2) * ((c.ch - 6 + 1) / 2);
                     }
                 }
             }
@@ -153,8 +158,7 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
         L.kp_cap = std::max(L.nfeat + 3, 4 * L.nini);
         L.kp_begin = kp_off;
         kp_off += L.kp_cap;
-        // default: the exact worst case (cannot overflow); max_cand_per_cell > 0 trades memory for an ORBX_CAPACITY risk
-        L.cand_cap = std::max(64, p.max_cand_per_cell > 0 ? std::min(nms_bound, L.cell_count * p.max_cand_per_cell) : nms_bound);
+        L.cand_cap = std::max(64, nms_bound);
         L.cand_begin = cand_off;
         cand_off += L.cand_cap;
         g.node_cap = std::max(g.node_cap, L.kp_cap + 8);

@@ -16,6 +16,8 @@ struct OrbxCell {
     int16_t offx, offy;      // j*wCell, i*hCell  (added to the sub-mat-local keypoint, :1540-1541)
     int16_t level;
     int16_t idx_in_level;    // row-major ordinal of the cell inside its level (emission order)
+    int32_t slot_begin;      // first candidate slot of this cell inside its level's candidate region
+    int32_t slot_cap;        // slots reserved: strict 3x3 maxima leave at most one survivor per 2x2 block
 };
 
 // resize tap for one padded destination coordinate (border folded in by reflect-101)

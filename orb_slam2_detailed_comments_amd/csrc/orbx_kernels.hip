@@ -39,29 +39,54 @@ __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restri
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const OrbxTap *__restrict__ taps,
                                                     uint8_t *__restrict__ pyr) {
+    // block = 64 x 4 threads; thread = 4 horizontally adjacent destination pixels (one dword store).
+    // The <= 8 source pixels a thread needs per source row sit inside 3 aligned dwords: 6 dword loads replace
+    // 16 byte gathers (byte-gather fallback for exotic scale factors whose footprint exceeds 12 bytes).
     const DLevel &L = g.lv[level];
     const DLevel &S = g.lv[level - 1];
-    const int X = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int Y = blockIdx.y;
+    const int X = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int Y = blockIdx.y * 4 + threadIdx.y;
     const int f = blockIdx.z;
-    if (X >= L.pw) return;
+    if (X >= L.pw || Y >= L.ph) return;
     uint8_t *base = pyr + (long long)f * g.pyr_bytes;
     const OrbxTap ty = taps[L.tapy + Y];
     const uint8_t *r0 = base + S.off + (long long)ty.s0 * S.pitch;
     const uint8_t *r1 = base + S.off + (long long)ty.s1 * S.pitch;
     const int b0 = ty.a0, b1 = ty.a1;
-    uint32_t v = 0;
+    OrbxTap tx[4];
+    int smin = 0x7fff, smax = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int x = X + i;
-        uint32_t p = 0;
-        if (x < L.pw) {
-            const OrbxTap tx = taps[L.tapx + x];
-            const int T0 = r0[tx.s0] * tx.a0 + r0[tx.s1] * tx.a1;
-            const int T1 = r1[tx.s0] * tx.a0 + r1[tx.s1] * tx.a1;
-            p = (uint32_t)((((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+        tx[i] = taps[L.tapx + min(X + i, L.pw - 1)];
+        smin = min(smin, (int)tx[i].s0);
+        smax = max(smax, (int)tx[i].s0);
+    }
+    const int xb = smin & ~3;
+    uint32_t v = 0;
+    if (smax + 1 - xb < 12) {
+        const uint32_t *q0 = (const uint32_t *)(r0 + xb), *q1 = (const uint32_t *)(r1 + xb);
+        const uint32_t u0 = q0[0], u1 = q0[1], u2 = q0[2];
+        const uint32_t w0 = q1[0], w1 = q1[1], w2 = q1[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tx[i].s0 - xb;  // 0..10; the second tap is the next byte (weight 0 whenever clamped)
+            const uint32_t ulo = idx < 4 ? u0 : idx < 8 ? u1 : u2, uhi = idx < 4 ? u1 : idx < 8 ? u2 : 0u;
+            const uint32_t wlo = idx < 4 ? w0 : idx < 8 ? w1 : w2, whi = idx < 4 ? w1 : idx < 8 ? w2 : 0u;
+            const uint32_t pu = __builtin_amdgcn_alignbyte(uhi, ulo, (uint32_t)idx & 3u);
+            const uint32_t pw_ = __builtin_amdgcn_alignbyte(whi, wlo, (uint32_t)idx & 3u);
+            const int T0 = (int)(pu & 0xff) * tx[i].a0 + (int)((pu >> 8) & 0xff) * tx[i].a1;
+            const int T1 = (int)(pw_ & 0xff) * tx[i].a0 + (int)((pw_ >> 8) & 0xff) * tx[i].a1;
+            const uint32_t p = (uint32_t)((((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+            v |= p << (8 * i);
         }
-        v |= p << (8 * i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int T0 = r0[tx[i].s0] * tx[i].a0 + r0[tx[i].s1] * tx[i].a1;
+            const int T1 = r1[tx[i].s0] * tx[i].a0 + r1[tx[i].s1] * tx[i].a1;
+            const uint32_t p = (uint32_t)((((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+            v |= p << (8 * i);
+        }
     }
     *(uint32_t *)(base + L.off + (long long)Y * L.pitch + X) = v;
 }
@@ -81,72 +106,127 @@ __device__ __forceinline__ bool orbx_arc9(uint32_t mask16) {
     return (a & 0xffffu) != 0;
 }
 
-// dynamic LDS: tile[rows*TP] | score[rows*TP] | list u16[lcap] | surv u32[scap]; TP = tile pitch (bytes, %4==0)
+// dynamic LDS: tile[rows*TP] | score[rows*TP] | listA u16[lcap] | listB u16[lcap] | corn u16[lcap] | surv u32[scap]
+// TP = tile pitch in bytes (multiple of 4)
+__device__ __forceinline__ int orbx_wave_compact(bool flag, uint16_t *list, int n, uint16_t value) {
+    const unsigned long long bal = __ballot(flag);
+    if (flag) {
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+        list[n + rank] = value;
+    }
+    return n + __popcll(bal);
+}
+
+// a 9-arc of the 16-ring contains at least one pixel of every opposite pair (k, k+8): necessary condition
+__device__ __forceinline__ bool orbx_compass(int v, int r0, int r4, int r8, int r12, int th) {
+    const int hi = v + th, lo = v - th;
+    const bool br = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi));
+    const bool dk = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo));
+    return br | dk;
+}
+
 __global__ __launch_bounds__(64) void k_fast_cells(DGeom g, const OrbxCell *__restrict__ cells,
                                                    const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
-                                                   int *__restrict__ cand_count, int FAST_TP, int rows, int lcap) {
+                                                   int *__restrict__ cell_count, int FAST_TP, int rows, int lcap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
+    const int lcap_b = (2 * lcap + 3) & ~3;
     uint32_t *s_tile = (uint32_t *)fast_smem;
     uint8_t *s_score = fast_smem + rows * FAST_TP;
-    uint16_t *s_list = (uint16_t *)(fast_smem + 2 * rows * FAST_TP);
-    uint32_t *s_surv = (uint32_t *)(fast_smem + 2 * rows * FAST_TP + ((2 * lcap + 3) & ~3));
+    uint16_t *s_listA = (uint16_t *)(fast_smem + 2 * rows * FAST_TP);
+    uint16_t *s_listB = (uint16_t *)(fast_smem + 2 * rows * FAST_TP + lcap_b);
+    uint16_t *s_corn = (uint16_t *)(fast_smem + 2 * rows * FAST_TP + 2 * lcap_b);
+    uint32_t *s_surv = (uint32_t *)(fast_smem + 2 * rows * FAST_TP + 3 * lcap_b);
     const int lane = threadIdx.x;
     const OrbxCell c = cells[blockIdx.x];
     const int f = blockIdx.y;
     const DLevel &L = g.lv[c.level];
     const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;
     const int cw = c.cw, ch = c.ch;
-    // ---- stage the tile with aligned dword loads
+    // ---- stage the tile with aligned dword loads (16 dword columns x 4 rows per wave step)
     const int xa = c.x0 & ~3, shift = c.x0 & 3;
     const int ndw = (shift + cw + 3) >> 2;
-    for (int i = lane; i < ch * ndw; i += 64) {
-        const int r = i / ndw, d = i - r * ndw;
-        s_tile[r * (FAST_TP / 4) + d] = *(const uint32_t *)(img + (long long)(c.y0 + r) * L.pitch + xa + 4 * d);
+    // all global loads are issued before the first LDS store (one exposed memory latency per cell, not one per row)
+    {
+        const int rq = lane >> 4, dq = lane & 15;
+        const uint8_t *src = img + (long long)c.y0 * L.pitch + xa + 4 * dq;
+        uint32_t tv[17];
+#pragma unroll
+        for (int k = 0; k < 17; ++k) {
+            const int r = 4 * k + rq;
+            tv[k] = (r < ch && dq < ndw) ? *(const uint32_t *)(src + (long long)r * L.pitch) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 17; ++k) {
+            const int r = 4 * k + rq;
+            if (r < ch && dq < ndw) s_tile[r * (FAST_TP / 4) + dq] = tv[k];
+        }
+        if (ndw > 16)  // cells wider than 61 px (tiny pyramid levels only)
+            for (int r = rq; r < ch; r += 4)
+                for (int d = 16 + dq; d < ndw; d += 16)
+                    s_tile[r * (FAST_TP / 4) + d] = *(const uint32_t *)(img + (long long)(c.y0 + r) * L.pitch + xa + 4 * d);
     }
+    for (int i = lane; i < ch * (FAST_TP / 4); i += 64) ((uint32_t *)s_score)[i] = 0;
     const uint8_t *tile = (const uint8_t *)s_tile + shift;
-    const int iw = cw - 6, ih = ch - 6, npix = iw * ih;
     // ring offsets in the LDS tile
     const int ro[16] = {3 * FAST_TP,      3 * FAST_TP + 1,  2 * FAST_TP + 2,  FAST_TP + 3, 3,  -FAST_TP + 3,
                         -2 * FAST_TP + 2, -3 * FAST_TP + 1, -3 * FAST_TP,     -3 * FAST_TP - 1, -2 * FAST_TP - 2,
                         -FAST_TP - 3,     -3,               FAST_TP - 3,      2 * FAST_TP - 2,  3 * FAST_TP - 1};
+    const int half = lane >> 5, lcol = lane & 31;
+    const bool two_th = g.min_th != g.ini_th;
+    __syncthreads();
+    // ---- phase 1a: compass pre-test of EVERY interior pixel at both thresholds in one sweep (two rows per lane
+    // per step for load-level parallelism); survivors are compacted so that the full ring test runs on dense lanes
+    int nA = 0, nB = 0;
+    for (int yb = 3; yb < ch - 3; yb += 4) {
+        for (int x0 = 3; x0 < cw - 3; x0 += 32) {
+            const int lx = x0 + lcol;
+            const int ly0 = yb + 2 * half, ly1 = ly0 + 1;
+            const bool act0 = lx < cw - 3 && ly0 < ch - 3, act1 = lx < cw - 3 && ly1 < ch - 3;
+            const uint8_t *p0 = tile + (act0 ? ly0 : 3) * FAST_TP + (act0 ? lx : 3);
+            const uint8_t *p1 = tile + (act1 ? ly1 : 3) * FAST_TP + (act1 ? lx : 3);
+            const int v0 = p0[0], a0 = p0[ro[0]], a4 = p0[ro[4]], a8 = p0[ro[8]], a12 = p0[ro[12]];
+            const int v1 = p1[0], b0 = p1[ro[0]], b4 = p1[ro[4]], b8 = p1[ro[8]], b12 = p1[ro[12]];
+            const bool A0 = act0 && orbx_compass(v0, a0, a4, a8, a12, g.ini_th);
+            const bool A1 = act1 && orbx_compass(v1, b0, b4, b8, b12, g.ini_th);
+            nA = orbx_wave_compact(A0, s_listA, nA, (uint16_t)((ly0 << 8) | lx));
+            nA = orbx_wave_compact(A1, s_listA, nA, (uint16_t)((ly1 << 8) | lx));
+            if (two_th) {
+                const bool B0 = act0 && orbx_compass(v0, a0, a4, a8, a12, g.min_th);
+                const bool B1 = act1 && orbx_compass(v1, b0, b4, b8, b12, g.min_th);
+                nB = orbx_wave_compact(B0, s_listB, nB, (uint16_t)((ly0 << 8) | lx));
+                nB = orbx_wave_compact(B1, s_listB, nB, (uint16_t)((ly1 << 8) | lx));
+            }
+        }
+    }
+    __syncthreads();
     int nsurv = 0;
     for (int pass = 0; pass < 2; ++pass) {
         const int th = pass == 0 ? g.ini_th : g.min_th;
-        for (int i = lane; i < ch * (FAST_TP / 4); i += 64) ((uint32_t *)s_score)[i] = 0;
-        __syncthreads();
-        // ---- phase 1: corner test, compact (lx,ly) of corners
+        const uint16_t *list = pass == 0 ? s_listA : s_listB;
+        const int nlist = pass == 0 ? nA : nB;
+        // ---- phase 1b: full 16-ring test of the pre-selected pixels
         int ncorn = 0;
-        for (int p0 = 0; p0 < npix; p0 += 64) {
-            const int p = p0 + lane;
-            bool corner = false;
-            int lx = 0, ly = 0;
-            if (p < npix) {
-                ly = p / iw;
-                lx = p - ly * iw + 3;
-                ly += 3;
-                const uint8_t *ptr = tile + ly * FAST_TP + lx;
-                const int v = ptr[0];
-                const int hi = v + th, lo = v - th;
-                uint32_t bright = 0, dark = 0;
+        for (int e0 = 0; e0 < nlist; e0 += 64) {
+            const int e = e0 + lane;
+            const bool valid = e < nlist;
+            const uint16_t code = valid ? list[e] : (uint16_t)((3 << 8) | 3);
+            const uint8_t *ptr = tile + (code >> 8) * FAST_TP + (code & 0xff);
+            const int v = ptr[0];
+            const int hi = v + th, lo = v - th;
+            uint32_t bright = 0, dark = 0;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int x = ptr[ro[k]];
-                    bright |= (uint32_t)(x > hi) << k;
-                    dark |= (uint32_t)(x < lo) << k;
-                }
-                corner = orbx_arc9(bright) || orbx_arc9(dark);
+            for (int k = 0; k < 16; ++k) {
+                const int x = ptr[ro[k]];
+                bright |= (uint32_t)(x > hi) << k;
+                dark |= (uint32_t)(x < lo) << k;
             }
-            const unsigned long long bal = __ballot(corner);
-            if (corner) {
-                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-                s_list[ncorn + rank] = (uint16_t)((ly << 8) | lx);
-            }
-            ncorn += __popcll(bal);
+            const bool corner = valid && (orbx_arc9(bright) || orbx_arc9(dark));
+            ncorn = orbx_wave_compact(corner, s_corn, ncorn, code);
         }
         __syncthreads();
-        // ---- phase 2: score of every compacted corner: max(th, max_arc min d, max_arc min -d) - 1
+        // ---- phase 2: score of every corner: max(th, max_arc min d, max_arc min -d) - 1
         for (int e = lane; e < ncorn; e += 64) {
-            const int lx = s_list[e] & 0xff, ly = s_list[e] >> 8;
+            const int lx = s_corn[e] & 0xff, ly = s_corn[e] >> 8;
             const uint8_t *ptr = tile + ly * FAST_TP + lx;
             const int v = ptr[0];
             int d[16];
@@ -166,8 +246,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(DGeom g, const OrbxCell *__re
                 a0 = max(a0, mn9);
                 b0 = min(b0, mx9);
             }
-            const int score = max(a0, -b0) - 1;
-            s_score[ly * FAST_TP + lx] = (uint8_t)score;
+            s_score[ly * FAST_TP + lx] = (uint8_t)(max(a0, -b0) - 1);
         }
         __syncthreads();
         // ---- phase 3: 3x3 strict NMS among the corners of THIS cell only
@@ -177,7 +256,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(DGeom g, const OrbxCell *__re
             bool keep = false;
             uint32_t rec = 0;
             if (e < ncorn) {
-                const int lx = s_list[e] & 0xff, ly = s_list[e] >> 8;
+                const int lx = s_corn[e] & 0xff, ly = s_corn[e] >> 8;
                 const uint8_t *sp = s_score + ly * FAST_TP + lx;
                 const int s = sp[0];
                 keep = s > sp[1] && s > sp[-1] && s > sp[-FAST_TP - 1] && s > sp[-FAST_TP] && s > sp[-FAST_TP + 1] &&
@@ -192,24 +271,22 @@ __global__ __launch_bounds__(64) void k_fast_cells(DGeom g, const OrbxCell *__re
             nsurv += __popcll(bal);
         }
         __syncthreads();
-        if (nsurv > 0 || g.min_th == g.ini_th) break;  // vKeysCell.empty() -> retry with minThFAST (:1519-1527)
+        if (nsurv > 0 || !two_th) break;  // vKeysCell.empty() -> retry with minThFAST (:1519-1527)
+        // the retry recomputes every score with the lower threshold: clear the scores of the first attempt
+        for (int e = lane; e < ncorn; e += 64) s_score[(s_corn[e] >> 8) * FAST_TP + (s_corn[e] & 0xff)] = 0;
+        __syncthreads();
     }
-    if (nsurv == 0) return;
-    // ---- emit: one atomic per cell reserves a contiguous block of candidate slots
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&cand_count[f * g.nlevels + c.level], nsurv);
-    base = __shfl(base, 0, 64);
-    uint2 *out = cand + (long long)f * g.cand_total + L.cand_begin;
-    for (int e = lane; e < nsurv; e += 64) {
+    // ---- emit into this cell's private slot range: no atomics, no dependence on other cells
+    if (lane == 0) cell_count[(long long)f * g.ncells + blockIdx.x] = nsurv;
+    uint2 *out = cand + (long long)f * g.cand_total + L.cand_begin + c.slot_begin;
+    const int nw = min(nsurv, c.slot_cap);
+    for (int e = lane; e < nw; e += 64) {
         const uint32_t rec = s_surv[e];
-        const int lx = rec & 0xff, ly = (rec >> 8) & 0xff, s = rec >> 16;
-        const int slot = base + e;
-        if (slot < L.cand_cap) {
-            uint2 o;
-            o.x = (uint32_t)(lx + c.offx) | ((uint32_t)(ly + c.offy) << 12) | ((uint32_t)s << 24);
-            o.y = ((uint32_t)c.idx_in_level << 12) | ((uint32_t)ly << 6) | (uint32_t)lx;  // emission order key
-            out[slot] = o;
-        }
+        const int lx = rec & 0xff, ly = (rec >> 8) & 0xff, sc = rec >> 16;
+        uint2 o;
+        o.x = (uint32_t)(lx + c.offx) | ((uint32_t)(ly + c.offy) << 12) | ((uint32_t)sc << 24);
+        o.y = ((uint32_t)c.idx_in_level << 12) | ((uint32_t)ly << 6) | (uint32_t)lx;  // emission order key
+        out[e] = o;
     }
 }
 
@@ -282,8 +359,10 @@ __device__ __forceinline__ void qt_child_box(uint32_t b0, uint32_t b1, int q, ui
     c1 = (uint32_t)cx1 | ((uint32_t)cy1 << 16);
 }
 
-__global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *__restrict__ cand_all,
-                                                        const int *__restrict__ cand_count,
+__global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell *__restrict__ cells,
+                                                        const uint2 *__restrict__ slots_all,
+                                                        const int *__restrict__ cell_count, uint2 *__restrict__ dense_all,
+                                                        int *__restrict__ cand_count,
                                                         uint32_t *__restrict__ lvl_kp, int *__restrict__ lvl_count,
                                                         int *__restrict__ status, uint16_t *__restrict__ knode_glob,
                                                         int ncap, int lds_keys) {
@@ -291,15 +370,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *_
     const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const DLevel &L = g.lv[level];
     const int N = L.nfeat;
-    int K = cand_count[f * g.nlevels + level];
-    if (K > L.cand_cap) {
-        if (tid == 0) atomicMax(&status[f], (int)ORBX_CAPACITY);
-        K = L.cand_cap;
-    }
-    const uint2 *cand = cand_all + (long long)f * g.cand_total + L.cand_begin;
+    const uint2 *slots = slots_all + (long long)f * g.cand_total + L.cand_begin;
+    uint2 *cand = dense_all + (long long)f * g.cand_total + L.cand_begin;
     // ---- LDS carve-up (all arrays have ncap entries unless noted)
     uint8_t *sp = qt_smem;
     QtShared *sh = (QtShared *)sp;                 sp += 128;
+    uint32_t *cscan = (uint32_t *)sp;              sp += 4 * QT_THREADS;      // per-thread cell-chunk totals / offsets
     unsigned long long *best = (unsigned long long *)sp; sp += 8 * (size_t)ncap;
     uint32_t *boxA0 = (uint32_t *)sp;              sp += 4 * (size_t)ncap;
     uint32_t *boxA1 = (uint32_t *)sp;              sp += 4 * (size_t)ncap;
@@ -317,11 +393,39 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *_
     uint32_t *t3 = (uint32_t *)sp;                 sp += 4 * (size_t)ncap;   // careful: rank / by-rank data
     uint32_t *t4 = (uint32_t *)sp;                 sp += 4 * (size_t)ncap;
     uint32_t *t5 = (uint32_t *)sp;                 sp += 4 * (size_t)ncap;
-    uint16_t *knode = (K <= lds_keys) ? (uint16_t *)sp
-                                      : knode_glob + ((long long)f * g.cand_total + L.cand_begin);
+    uint16_t *knode_lds = (uint16_t *)sp;
     uint32_t *box0 = boxA0, *box1 = boxA1, *cnt = cntA, *meta = metaA;
     uint32_t *nbox0 = boxB0, *nbox1 = boxB1, *ncnt = cntB, *nmeta = metaB;
 
+    // ---- gather: the FAST kernel left every cell's survivors in the cell's own slot range; pack them into a
+    // dense key array (cell order, so the result is independent of scheduling).  thread = a chunk of cells.
+    const int nc = L.cell_count;
+    const int chunk = (nc + QT_THREADS - 1) / QT_THREADS;
+    const int c_begin = min(tid * chunk, nc), c_end = min(c_begin + chunk, nc);
+    {
+        uint32_t mine = 0;
+        for (int i = c_begin; i < c_end; ++i) {
+            int c = cell_count[(long long)f * g.ncells + L.cell_begin + i];
+            const int cap = cells[L.cell_begin + i].slot_cap;
+            if (c > cap) { atomicMax(&status[f], (int)ORBX_CAPACITY); c = cap; }
+            mine += (uint32_t)c;
+        }
+        cscan[tid] = mine;
+    }
+    __syncthreads();
+    const int K = (int)qt_block_scan(cscan, cscan, QT_THREADS, sh);
+    {
+        uint32_t o = cscan[tid];
+        for (int i = c_begin; i < c_end; ++i) {
+            const OrbxCell cl = cells[L.cell_begin + i];
+            const int c = min(cell_count[(long long)f * g.ncells + L.cell_begin + i], cl.slot_cap);
+            for (int e = 0; e < c; ++e) cand[o + e] = slots[cl.slot_begin + e];
+            o += (uint32_t)c;
+        }
+    }
+    if (tid == 0) cand_count[f * g.nlevels + level] = K;
+    uint16_t *knode = (K <= lds_keys) ? knode_lds : knode_glob + ((long long)f * g.cand_total + L.cand_begin);
+    __syncthreads();
     // ---- roots (:1060-1135)
     const int nini = L.nini;
     const float hx = L.hx;
@@ -497,12 +601,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *_
 // K4: IC_Angle (reference src/ORBextractor.cc:104-161): one wave per keypoint slot; lanes 0-31 take the
 // row +v, lanes 32-63 the row -v; integer moments reduced across the wave; fastAtan2 on every lane.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool orbx_slot_to_level(const DGeom &g, int slot, const int *lvl_count_f, int &level, int &idx) {
+__device__ __forceinline__ void orbx_slot_to_level(const DGeom &g, int slot, int &level, int &idx) {
     level = 0;
-    for (int l = 0; l < g.nlevels; ++l)
-        if (slot >= g.lv[l].kp_begin) level = l;
+#pragma unroll
+    for (int l = 1; l < ORBX_MAX_LEVELS; ++l)
+        if (l < g.nlevels && slot >= g.lv[l].kp_begin) level = l;
     idx = slot - g.lv[level].kp_begin;
-    return idx < lvl_count_f[level];
 }
 
 __global__ __launch_bounds__(256) void k_orient(DGeom g, const uint8_t *__restrict__ pyr,
@@ -513,22 +617,26 @@ __global__ __launch_bounds__(256) void k_orient(DGeom g, const uint8_t *__restri
     const int f = blockIdx.y;
     if (slot >= g.kp_total) return;
     int level, idx;
-    if (!orbx_slot_to_level(g, slot, lvl_count + f * g.nlevels, level, idx)) return;
+    orbx_slot_to_level(g, slot, level, idx);
+    const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];       // issued together with the count load
+    const int count = lvl_count[f * g.nlevels + level];
+    if (idx >= count) return;
     const DLevel &L = g.lv[level];
-    const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];
     const int x = (int)(pos & 0xfff) + (ORBX_EDGE - 3), y = (int)((pos >> 12) & 0xfff) + (ORBX_EDGE - 3);
     const uint8_t *center = pyr + (long long)f * g.pyr_bytes + L.off + (long long)y * L.pitch + x;
-    int m10 = 0, m01 = 0;
     const int u = (lane & 31) - ORBX_HALF_PATCH;  // -15..16
-    if (lane < 31) m10 += u * (int)center[u];     // row v = 0
     const int sgn = lane < 32 ? 1 : -1;
+    // 16 independent byte loads per lane (every address is inside the padded image: |u| <= 16, |v| <= 15 < 19)
+    int vals[ORBX_HALF_PATCH + 1];
+#pragma unroll
+    for (int v = 0; v <= ORBX_HALF_PATCH; ++v) vals[v] = center[u + sgn * v * L.pitch];
+    int m10 = lane < 31 ? u * vals[0] : 0, m01 = 0;
+#pragma unroll
     for (int v = 1; v <= ORBX_HALF_PATCH; ++v) {
         const int d = g.umax[v];
-        if (u >= -d && u <= d) {
-            const int val = center[u + sgn * v * L.pitch];
-            m10 += u * val;
-            m01 += sgn * v * val;
-        }
+        const int val = (u >= -d && u <= d) ? vals[v] : 0;
+        m10 += u * val;
+        m01 += sgn * v * val;
     }
     m10 = orbx_wave_sum(m10);
     m01 = orbx_wave_sum(m01);
@@ -540,11 +648,13 @@ __global__ __launch_bounds__(256) void k_orient(DGeom g, const uint8_t *__restri
 // SSE2 column path: columns x < (w & ~3) accumulate in float with round-to-nearest-even, the last
 // (w & 3) columns use the integer (s + 2^15) >> 16 tail).  Tile 64x16 per 256-thread block, staged in LDS.
 // ------------------------------------------------------------------------------------------------
-#define BL_TW 64
-#define BL_TH 16
+#define BL_TW 128
+#define BL_TH 32
+#define BL_SD ((BL_TW + 8) / 4)  // staged dwords per row: pixels [X0-4, X0+TW+4)
+#define BL_ROWS (BL_TH + 6)
 __global__ __launch_bounds__(256) void k_blur(DGeom g, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur) {
-    __shared__ uint8_t s_src[(BL_TH + 6) * (BL_TW + 8)];
-    __shared__ uint16_t s_h[(BL_TH + 6) * BL_TW];
+    __shared__ uint32_t s_src[BL_ROWS * BL_SD];
+    __shared__ __attribute__((aligned(8))) uint16_t s_h[BL_ROWS * BL_TW];
     const int tid = threadIdx.x, f = blockIdx.y;
     int level = 0;
     for (int l = 0; l < g.nlevels; ++l)
@@ -554,48 +664,80 @@ __global__ __launch_bounds__(256) void k_blur(DGeom g, const uint8_t *__restrict
     const int ty = t / L.blur_tx, tx = t - ty * L.blur_tx;
     const int X0 = tx * BL_TW, Y0 = ty * BL_TH;
     const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;
-    // stage (TH+6) x (TW+6) source pixels, reflect-101 at the padded image bounds
-    for (int i = tid; i < (BL_TH + 6) * (BL_TW + 6); i += 256) {
-        const int r = i / (BL_TW + 6), c = i - r * (BL_TW + 6);
-        const int sy = orbx_reflect101(Y0 + r - 3, L.ph), sx = orbx_reflect101(X0 + c - 3, L.pw);
-        s_src[r * (BL_TW + 8) + c] = img[(long long)sy * L.pitch + sx];
+    // ---- stage (TH+6) rows of (TW+8) pixels as aligned dwords; reflect-101 only on tiles touching the image edge
+    for (int i = tid; i < BL_ROWS * BL_SD; i += 256) {
+        const int r = i / BL_SD, d = i - r * BL_SD;
+        const int sy = orbx_reflect101(Y0 + r - 3, L.ph);
+        const int x = X0 - 4 + 4 * d;
+        const uint8_t *row = img + (long long)sy * L.pitch;
+        uint32_t v;
+        if (x >= 0 && x + 3 < L.pw) {
+            v = *(const uint32_t *)(row + x);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v |= (uint32_t)row[orbx_reflect101(x + k, L.pw)] << (8 * k);
+        }
+        s_src[i] = v;
     }
     __syncthreads();
-    // row pass: kernel {18,34,49,55,49,34,18} (float Gaussian * 256, rounded; sums to 257)
-    for (int i = tid; i < (BL_TH + 6) * BL_TW; i += 256) {
-        const int r = i / BL_TW, c = i - r * BL_TW;
-        const uint8_t *s = s_src + r * (BL_TW + 8) + c;
-        const int acc = 18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 49 * (s[2] + s[4]) + 55 * s[3];
-        s_h[i] = (uint16_t)acc;  // <= 255 * 257 = 65535
+    // ---- row pass: kernel {18,34,49,55,49,34,18} (float Gaussian * 256, rounded; sums to 257); 4 pixels per item
+    for (int i = tid; i < BL_ROWS * (BL_TW / 4); i += 256) {
+        const int r = i >> 5, q = i & 31;
+        const uint32_t *w = s_src + r * BL_SD + q;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        int b[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            b[k] = (w0 >> (8 * k)) & 0xff; b[4 + k] = (w1 >> (8 * k)) & 0xff; b[8 + k] = (w2 >> (8 * k)) & 0xff;
+        }
+        uint32_t h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            h[j] = 18 * (b[j + 1] + b[j + 7]) + 34 * (b[j + 2] + b[j + 6]) + 49 * (b[j + 3] + b[j + 5]) + 55 * b[j + 4];
+        uint2 o;
+        o.x = h[0] | (h[1] << 16);  // each <= 255 * 257 = 65535
+        o.y = h[2] | (h[3] << 16);
+        *(uint2 *)(s_h + r * BL_TW + 4 * q) = o;
     }
     __syncthreads();
-    // column pass: 4 horizontally adjacent outputs per thread
-    const int cx = (tid & 15) * 4, cy = tid >> 4;
-    const int Y = Y0 + cy;
-    if (Y >= L.ph || X0 + cx >= L.pw) return;
+    // ---- column pass: thread = 4 columns x 4 rows (10 staged rows), one dword store per output row
+    const int cg = tid & 31, rg = tid >> 5;
+    const int X = X0 + 4 * cg;
+    if (X >= L.pw) return;
     const int wv = L.pw & ~3;
     const float k0 = 55.f / 65536.f, k1 = 49.f / 65536.f, k2 = 34.f / 65536.f, k3 = 18.f / 65536.f;
-    uint32_t outv = 0;
+    int hh[10][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int X = X0 + cx + i;
-        const uint16_t *h = s_h + cy * BL_TW + cx + i;
-        const int r0 = h[3 * BL_TW], r1 = h[2 * BL_TW] + h[4 * BL_TW], r2 = h[1 * BL_TW] + h[5 * BL_TW],
-                  r3 = h[0] + h[6 * BL_TW];
-        int o;
-        if (X < wv) {
-            float s0 = (float)r0 * k0 + 0.f;
-            s0 = s0 + (float)r1 * k1;
-            s0 = s0 + (float)r2 * k2;
-            s0 = s0 + (float)r3 * k3;
-            o = (int)__builtin_rintf(s0);
-        } else {
-            o = (55 * r0 + 49 * r1 + 34 * r2 + 18 * r3 + (1 << 15)) >> 16;
-        }
-        o = min(max(o, 0), 255);
-        outv |= (uint32_t)o << (8 * i);
+    for (int r = 0; r < 10; ++r) {
+        const uint2 v = *(const uint2 *)(s_h + (rg * 4 + r) * BL_TW + 4 * cg);
+        hh[r][0] = v.x & 0xffff; hh[r][1] = v.x >> 16; hh[r][2] = v.y & 0xffff; hh[r][3] = v.y >> 16;
     }
-    *(uint32_t *)(blur + (long long)f * g.pyr_bytes + L.off + (long long)Y * L.pitch + X0 + cx) = outv;
+    uint8_t *out = blur + (long long)f * g.pyr_bytes + L.off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int Y = Y0 + rg * 4 + j;
+        if (Y >= L.ph) break;
+        uint32_t outv = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r0 = hh[j + 3][i], r1 = hh[j + 2][i] + hh[j + 4][i], r2 = hh[j + 1][i] + hh[j + 5][i],
+                      r3 = hh[j][i] + hh[j + 6][i];
+            int o;
+            if (X + i < wv) {
+                float s0 = (float)r0 * k0 + 0.f;
+                s0 = s0 + (float)r1 * k1;
+                s0 = s0 + (float)r2 * k2;
+                s0 = s0 + (float)r3 * k3;
+                o = (int)__builtin_rintf(s0);
+            } else {
+                o = (55 * r0 + 49 * r1 + 34 * r2 + 18 * r3 + (1 << 15)) >> 16;
+            }
+            o = min(max(o, 0), 255);
+            outv |= (uint32_t)o << (8 * i);
+        }
+        *(uint32_t *)(out + (long long)Y * L.pitch + X) = outv;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -603,7 +745,8 @@ __global__ __launch_bounds__(256) void k_blur(DGeom g, const uint8_t *__restrict
 // One wave per keypoint slot; 4 rounds x 64 lanes, one test pair per lane; __ballot packs 64 descriptor
 // bits per round in the reference's bit order (bit i of byte j = pair 8j+i  ==  little-endian u64 words).
 // ------------------------------------------------------------------------------------------------
-__constant__ signed char c_pattern[1024];
+// pattern rearranged per lane: entry l holds, for round r = 0..3, the pair r*64 + l as (x1, y1, x2, y2) int8
+__constant__ int4 c_pattern_lane[64];
 
 __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__restrict__ blur,
                                                   const uint32_t *__restrict__ lvl_kp,
@@ -615,39 +758,45 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int f = blockIdx.y;
     if (slot >= g.kp_total) return;
-    const int *lc = lvl_count + f * g.nlevels;
     int level, idx;
-    const bool valid = orbx_slot_to_level(g, slot, lc, level, idx);
-    int before = 0, total = 0;
-    for (int l = 0; l < g.nlevels; ++l) {
-        const int c = lc[l];
-        if (l < level) before += c;
-        total += c;
+    orbx_slot_to_level(g, slot, level, idx);
+    // independent loads first: position, angle, this lane's 8 pattern points, the per-level counts
+    const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];
+    const float angle_deg = lvl_angle[(long long)f * g.kp_total + slot];
+    const int4 pat = c_pattern_lane[lane];
+    const int *lc = lvl_count + f * g.nlevels;
+    int before = 0, total = 0, mine = 0;
+#pragma unroll
+    for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
+        if (l < g.nlevels) {
+            const int c = lc[l];
+            if (l < level) before += c;
+            if (l == level) mine = c;
+            total += c;
+        }
     }
     if (slot == 0 && lane == 0) {
         counts[f] = min(total, cap);
         if (total > cap) atomicMax(&status[f], (int)ORBX_CAPACITY);
     }
-    if (!valid) return;
+    if (idx >= mine) return;
     const int oi = before + idx;
     if (oi >= cap) return;
     const DLevel &L = g.lv[level];
-    const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];
     const int x = (int)(pos & 0xfff) + (ORBX_EDGE - 3), y = (int)((pos >> 12) & 0xfff) + (ORBX_EDGE - 3);
-    const float angle_deg = lvl_angle[(long long)f * g.kp_total + slot];
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float angle = angle_deg * factorPI;
     const OrbxSinCos sc = orbx_sincosf_pinned(angle);
     const float a = sc.c, b = sc.s;
     const uint8_t *center = blur + (long long)f * g.pyr_bytes + L.off + (long long)y * L.pitch + x;
-    unsigned long long words[4];
+    const int pw4[4] = {pat.x, pat.y, pat.z, pat.w};
+    int tv[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int pair = r * 64 + lane;
-        int tv[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const float px = (float)c_pattern[4 * pair + 2 * s], py = (float)c_pattern[4 * pair + 2 * s + 1];
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const float px = (float)(signed char)((pw4[r] >> (16 * s2)) & 0xff);
+            const float py = (float)(signed char)((pw4[r] >> (16 * s2 + 8)) & 0xff);
             float fy, fx;
             if (g.fp_mode == ORBX_FP_GCC_FMA) {
                 fy = __builtin_fmaf(px, b, py * a);     // vfmadd132ss: x*b + rn(y*a)
@@ -657,10 +806,12 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
                 fx = px * a - py * b;
             }
             const int iy = (int)__builtin_rintf(fy), ix = (int)__builtin_rintf(fx);
-            tv[s] = center[iy * L.pitch + ix];
+            tv[2 * r + s2] = center[iy * L.pitch + ix];
         }
-        words[r] = __ballot(tv[0] < tv[1]);
     }
+    unsigned long long words[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) words[r] = __ballot(tv[2 * r] < tv[2 * r + 1]);
     if (lane < 4) {
         unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
         *(unsigned long long *)(desc + ((long long)f * cap + oi) * 32 + 8 * lane) = w;
@@ -684,38 +835,53 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
 // pair; bookkeeping of the search loops, e.g. :627-640).  One query per lane (8 dwords in VGPRs), train
 // descriptors staged through LDS in tiles and read as wave-wide broadcasts; v_xor + v_bcnt accumulate.
 // ------------------------------------------------------------------------------------------------
-#define MT_TILE 256
-__global__ __launch_bounds__(64) void k_match(int npairs, const uint8_t *__restrict__ q, const int *__restrict__ nq,
-                                              long long q_stride, const uint8_t *__restrict__ t,
-                                              const int *__restrict__ nt, long long t_stride,
-                                              int *__restrict__ best_idx, int *__restrict__ best_dist,
-                                              int *__restrict__ second_dist, int out_stride) {
-    __shared__ uint4 s_t[MT_TILE * 2];
-    const int lane = threadIdx.x, pr = blockIdx.y;
-    const int NQ = nq[pr], NT = nt[pr];
+#define MT_SPLIT 4
+__global__ __launch_bounds__(64 * MT_SPLIT) void k_match(int npairs, const uint8_t *__restrict__ q,
+                                                         const int *__restrict__ nq, long long q_stride,
+                                                         const uint8_t *__restrict__ t, const int *__restrict__ nt,
+                                                         long long t_stride, int *__restrict__ best_idx,
+                                                         int *__restrict__ best_dist, int *__restrict__ second_dist,
+                                                         int out_stride) {
+    // block = MT_SPLIT waves; every wave holds the same 64 queries (one per lane, 8 dwords in VGPRs) and scans
+    // its own quarter of the train set.  The train descriptor address is wave-uniform, so it is fetched through
+    // the scalar cache (s_load) and used as an SGPR operand of v_xor: no LDS staging, no barriers in the loop.
+    // key = dist << 20 | index: min(key) is the best match with the lowest index on ties; the second-smallest
+    // key carries the second-best distance (counting duplicates), exactly the bookkeeping of the reference loops.
+    __shared__ uint32_t s_best[MT_SPLIT][64], s_second[MT_SPLIT][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pr = blockIdx.y;
+    const int NQ = nq[pr], NT = min(nt[pr], 1 << 20);
     const int qi = blockIdx.x * 64 + lane;
-    if (blockIdx.x * 64 >= NQ) return;
+    if ((int)blockIdx.x * 64 >= NQ) return;
     const uint4 *qp = (const uint4 *)(q + (long long)pr * q_stride);
     const uint4 *tp = (const uint4 *)(t + (long long)pr * t_stride);
     uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
     if (qi < NQ) { qa = qp[2 * qi]; qb = qp[2 * qi + 1]; }
-    int bd = 0x7fffffff, bd2 = 0x7fffffff, bi = -1;
-    for (int t0 = 0; t0 < NT; t0 += MT_TILE) {
-        const int n = min(MT_TILE, NT - t0);
-        __syncthreads();
-        for (int i = lane; i < 2 * n; i += 64) s_t[i] = tp[2 * t0 + i];
-        __syncthreads();
-        for (int j = 0; j < n; ++j) {
-            const uint4 ta = s_t[2 * j], tb = s_t[2 * j + 1];
-            int d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
-                    __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
-            if (d < bd) { bd2 = bd; bd = d; bi = t0 + j; }
-            else if (d < bd2) bd2 = d;
-        }
+    const int chunk = (NT + MT_SPLIT - 1) / MT_SPLIT;
+    const int j0 = __builtin_amdgcn_readfirstlane(w * chunk), j1 = min(NT, j0 + chunk);
+    uint32_t best = 0xffffffffu, second = 0xffffffffu;
+#pragma unroll 8
+    for (int j = j0; j < j1; ++j) {
+        const uint4 ta = tp[2 * j], tb = tp[2 * j + 1];
+        const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                           __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+        const uint32_t key = (d << 20) | (uint32_t)j;
+        second = min(second, max(best, key));
+        best = min(best, key);
     }
-    if (qi < NQ) {
+    s_best[w][lane] = best;
+    s_second[w][lane] = second;
+    __syncthreads();
+    if (w == 0 && qi < NQ) {
+#pragma unroll
+        for (int k = 1; k < MT_SPLIT; ++k) {
+            const uint32_t bk = s_best[k][lane], sk = s_second[k][lane];
+            second = min(min(second, sk), max(best, bk));
+            best = min(best, bk);
+        }
         const long long o = (long long)pr * out_stride + qi;
-        best_idx[o] = bi; best_dist[o] = bd; second_dist[o] = bd2;
+        best_idx[o] = best == 0xffffffffu ? -1 : (int)(best & 0xfffffu);
+        best_dist[o] = best == 0xffffffffu ? 0x7fffffff : (int)(best >> 20);
+        second_dist[o] = second == 0xffffffffu ? 0x7fffffff : (int)(second >> 20);
     }
 }
 
@@ -746,11 +912,15 @@ __global__ void k_clear(int *a, int na, int *b, int nb, int *c, int nc) {
 #include "orbx_launch.h"
 
 hipError_t orbx_upload_pattern() {
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ORBX_PATTERN_I8, 1024);
+    signed char t[64 * 16];
+    for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < 4; ++r)
+            for (int k = 0; k < 4; ++k) t[l * 16 + r * 4 + k] = ORBX_PATTERN_I8[(r * 64 + l) * 4 + k];
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_pattern_lane), t, sizeof(t));
 }
 
 size_t orbx_quadtree_smem(int ncap, int lds_keys) {
-    return 128 + (size_t)ncap * (8 + 8 * 4 + 16 + 16 + 6 * 4) + (size_t)lds_keys * 2 + 16;
+    return 128 + 4 * QT_THREADS + (size_t)ncap * (8 + 8 * 4 + 16 + 16 + 6 * 4) + (size_t)lds_keys * 2 + 16;
 }
 
 void orbx_launch_clear(hipStream_t s, int *a, int na, int *b, int nb, int *c, int nc) {
@@ -765,25 +935,25 @@ void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *img
 }
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr) {
     const DLevel &L = g.lv[level];
-    dim3 grid((L.pitch / 4 + 255) / 256, L.ph, B);
-    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, g, level, taps, pyr);
+    dim3 grid((L.pw + 255) / 256, (L.ph + 3) / 4, B);
+    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, g, level, taps, pyr);
 }
 void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint8_t *pyr, uint2 *cand,
-                      int *cand_count, int max_cw, int max_ch) {
+                      int *cell_count, int max_cw, int max_ch) {
     if (g.ncells == 0) return;
     const int tp = (max_cw + 3 + 3) & ~3;           // +3: dword-alignment shift of the tile origin
     const int lcap = (max_cw - 6) * (max_ch - 6);   // every interior pixel could be a corner
     const int scap = ((max_cw - 6 + 1) / 2) * ((max_ch - 6 + 1) / 2);  // strict 3x3 maxima: <= 1 per 2x2 block
-    const size_t smem = (size_t)2 * max_ch * tp + ((2 * lcap + 3) & ~3) + 4 * (size_t)scap;
-    hipLaunchKernelGGL(k_fast_cells, dim3(g.ncells, B), dim3(64), smem, s, g, cells, pyr, cand, cand_count, tp,
+    const size_t smem = (size_t)2 * max_ch * tp + 3 * (size_t)((2 * lcap + 3) & ~3) + 4 * (size_t)scap;
+    hipLaunchKernelGGL(k_fast_cells, dim3(g.ncells, B), dim3(64), smem, s, g, cells, pyr, cand, cell_count, tp,
                        max_ch, lcap);
 }
-void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const uint2 *cand, const int *cand_count,
-                          uint32_t *lvl_kp, int *lvl_count, int *status, uint16_t *knode_glob, int ncap,
-                          int lds_keys) {
+void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
+                          const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,
+                          int *status, uint16_t *knode_glob, int ncap, int lds_keys) {
     const size_t smem = orbx_quadtree_smem(ncap, lds_keys);
-    hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, B), dim3(QT_THREADS), smem, s, g, cand, cand_count, lvl_kp,
-                       lvl_count, status, knode_glob, ncap, lds_keys);
+    hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, B), dim3(QT_THREADS), smem, s, g, cells, slots, cell_count, dense,
+                       cand_count, lvl_kp, lvl_count, status, knode_glob, ncap, lds_keys);
 }
 hipError_t orbx_quadtree_prepare(size_t smem) {
     return hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -805,7 +975,7 @@ void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, 
                        const uint8_t *t, const int *nt, long long t_stride, int *best_idx, int *best_dist,
                        int *second_dist, int out_stride) {
     if (npairs <= 0 || max_nq <= 0) return;
-    hipLaunchKernelGGL(k_match, dim3((max_nq + 63) / 64, npairs), dim3(64), 0, s, npairs, q, nq, q_stride, t, nt,
+    hipLaunchKernelGGL(k_match, dim3((max_nq + 63) / 64, npairs), dim3(64 * MT_SPLIT), 0, s, npairs, q, nq, q_stride, t, nt,
                        t_stride, best_idx, best_dist, second_dist, out_stride);
 }
 void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *dist) {

@@ -11,10 +11,10 @@ void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *img
                         long long frame_stride, uint8_t *pyr);
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr);
 void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint8_t *pyr, uint2 *cand,
-                      int *cand_count, int max_cw, int max_ch);
-void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const uint2 *cand, const int *cand_count,
-                          uint32_t *lvl_kp, int *lvl_count, int *status, uint16_t *knode_glob, int ncap,
-                          int lds_keys);
+                      int *cell_count, int max_cw, int max_ch);
+void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
+                          const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,
+                          int *status, uint16_t *knode_glob, int ncap, int lds_keys);
 void orbx_launch_orient(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
                         const int *lvl_count, float *lvl_angle);
 void orbx_launch_blur(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, uint8_t *blur);
