@@ -120,9 +120,9 @@ __device__ __forceinline__ int orbx_wave_compact(bool flag, uint16_t *list, int 
 // a 9-arc of the 16-ring contains at least one pixel of every opposite pair (k, k+8): necessary condition
 __device__ __forceinline__ bool orbx_compass(int v, int r0, int r4, int r8, int r12, int th) {
     const int hi = v + th, lo = v - th;
-    const bool br = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi));
-    const bool dk = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo));
-    return br | dk;
+    const int br = ((int)(r0 > hi) | (int)(r8 > hi)) & ((int)(r4 > hi) | (int)(r12 > hi));
+    const int dk = ((int)(r0 < lo) | (int)(r8 < lo)) & ((int)(r4 < lo) | (int)(r12 < lo));
+    return (br | dk) != 0;
 }
 
 __global__ __launch_bounds__(64) void k_fast_cells(DGeom g, const OrbxCell *__restrict__ cells,
@@ -148,18 +148,19 @@ __global__ __launch_bounds__(64) void k_fast_cells(DGeom g, const OrbxCell *__re
     // all global loads are issued before the first LDS store (one exposed memory latency per cell, not one per row)
     {
         const int rq = lane >> 4, dq = lane & 15;
-        const uint8_t *src = img + (long long)c.y0 * L.pitch + xa + 4 * dq;
         uint32_t tv[17];
+        const int dqc = min(dq, ndw - 1);
+        const uint8_t *srcc = img + (long long)c.y0 * L.pitch + xa + 4 * dqc;
 #pragma unroll
-        for (int k = 0; k < 17; ++k) {
-            const int r = 4 * k + rq;
-            tv[k] = (r < ch && dq < ndw) ? *(const uint32_t *)(src + (long long)r * L.pitch) : 0u;
-        }
+        for (int k = 0; k < 17; ++k)
+            if (4 * k < ch)  // wave-uniform; rows past the cell are clamped (re-read), never out of bounds
+                tv[k] = *(const uint32_t *)(srcc + (long long)min(4 * k + rq, ch - 1) * L.pitch);
 #pragma unroll
-        for (int k = 0; k < 17; ++k) {
-            const int r = 4 * k + rq;
-            if (r < ch && dq < ndw) s_tile[r * (FAST_TP / 4) + dq] = tv[k];
-        }
+        for (int k = 0; k < 17; ++k)
+            if (4 * k < ch) {
+                const int r = 4 * k + rq;
+                if (r < ch && dq < ndw) s_tile[r * (FAST_TP / 4) + dq] = tv[k];
+            }
         if (ndw > 16)  // cells wider than 61 px (tiny pyramid levels only)
             for (int r = rq; r < ch; r += 4)
                 for (int d = 16 + dq; d < ndw; d += 16)
@@ -186,13 +187,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(DGeom g, const OrbxCell *__re
             const uint8_t *p1 = tile + (act1 ? ly1 : 3) * FAST_TP + (act1 ? lx : 3);
             const int v0 = p0[0], a0 = p0[ro[0]], a4 = p0[ro[4]], a8 = p0[ro[8]], a12 = p0[ro[12]];
             const int v1 = p1[0], b0 = p1[ro[0]], b4 = p1[ro[4]], b8 = p1[ro[8]], b12 = p1[ro[12]];
-            const bool A0 = act0 && orbx_compass(v0, a0, a4, a8, a12, g.ini_th);
-            const bool A1 = act1 && orbx_compass(v1, b0, b4, b8, b12, g.ini_th);
+            const bool A0 = (int)act0 & (int)orbx_compass(v0, a0, a4, a8, a12, g.ini_th);
+            const bool A1 = (int)act1 & (int)orbx_compass(v1, b0, b4, b8, b12, g.ini_th);
             nA = orbx_wave_compact(A0, s_listA, nA, (uint16_t)((ly0 << 8) | lx));
             nA = orbx_wave_compact(A1, s_listA, nA, (uint16_t)((ly1 << 8) | lx));
             if (two_th) {
-                const bool B0 = act0 && orbx_compass(v0, a0, a4, a8, a12, g.min_th);
-                const bool B1 = act1 && orbx_compass(v1, b0, b4, b8, b12, g.min_th);
+                const bool B0 = (int)act0 & (int)orbx_compass(v0, a0, a4, a8, a12, g.min_th);
+                const bool B1 = (int)act1 & (int)orbx_compass(v1, b0, b4, b8, b12, g.min_th);
                 nB = orbx_wave_compact(B0, s_listB, nB, (uint16_t)((ly0 << 8) | lx));
                 nB = orbx_wave_compact(B1, s_listB, nB, (uint16_t)((ly1 << 8) | lx));
             }
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(DGeom g, const OrbxCell *__re
                 bright |= (uint32_t)(x > hi) << k;
                 dark |= (uint32_t)(x < lo) << k;
             }
-            const bool corner = valid && (orbx_arc9(bright) || orbx_arc9(dark));
+            const bool corner = (int)valid & ((int)orbx_arc9(bright) | (int)orbx_arc9(dark));
             ncorn = orbx_wave_compact(corner, s_corn, ncorn, code);
         }
         __syncthreads();
@@ -253,16 +254,16 @@ __global__ __launch_bounds__(64) void k_fast_cells(DGeom g, const OrbxCell *__re
         nsurv = 0;
         for (int e0 = 0; e0 < ncorn; e0 += 64) {
             const int e = e0 + lane;
-            bool keep = false;
-            uint32_t rec = 0;
-            if (e < ncorn) {
-                const int lx = s_corn[e] & 0xff, ly = s_corn[e] >> 8;
-                const uint8_t *sp = s_score + ly * FAST_TP + lx;
-                const int s = sp[0];
-                keep = s > sp[1] && s > sp[-1] && s > sp[-FAST_TP - 1] && s > sp[-FAST_TP] && s > sp[-FAST_TP + 1] &&
-                       s > sp[FAST_TP - 1] && s > sp[FAST_TP] && s > sp[FAST_TP + 1];
-                rec = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)s << 16);
-            }
+            const bool valid = e < ncorn;
+            const uint16_t code = valid ? s_corn[e] : (uint16_t)((3 << 8) | 3);
+            const int lx = code & 0xff, ly = code >> 8;
+            const uint8_t *sp = s_score + ly * FAST_TP + lx;
+            const int sc = sp[0];
+            const int n0 = sp[1], n1 = sp[-1], n2 = sp[-FAST_TP - 1], n3 = sp[-FAST_TP], n4 = sp[-FAST_TP + 1],
+                      n5 = sp[FAST_TP - 1], n6 = sp[FAST_TP], n7 = sp[FAST_TP + 1];
+            const bool keep = (int)valid & (int)(sc > n0) & (int)(sc > n1) & (int)(sc > n2) & (int)(sc > n3) &
+                              (int)(sc > n4) & (int)(sc > n5) & (int)(sc > n6) & (int)(sc > n7);
+            const uint32_t rec = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)sc << 16);
             const unsigned long long bal = __ballot(keep);
             if (keep) {
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
