@@ -125,6 +125,32 @@ orbx_status orbx_match_bruteforce(orbx_handle *h, const uint8_t *q, int nq, cons
 orbx_status orbx_hamming_matrix(orbx_handle *h, const uint8_t *q, int nq, const uint8_t *t, int nt,
                                 uint16_t *dist);
 
+/* ---- matcher policies on the path ------------------------- */
+/* Frame::AssignFeaturesToGrid + PosInGrid (src/Frame.cc:432-460, 729-745): 64 x 48 buckets over keypoints that the
+ * caller keeps alive; bounds = mnMinX, mnMaxX, mnMinY, mnMaxY.  Host-side (the reference keeps it host-side too). */
+typedef struct orbx_grid orbx_grid;
+orbx_grid *orbx_grid_create(const orbx_keypoint *kps, int n, float min_x, float max_x, float min_y, float max_y);
+void orbx_grid_destroy(orbx_grid *g);
+/* Frame::GetFeaturesInArea (src/Frame.cc:633-717); returns the number of hits (may exceed cap), < 0 on error */
+int orbx_grid_query(const orbx_grid *g, float x, float y, float r, int min_level, int max_level, int32_t *out, int cap);
+/* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:2026-2068) */
+void orbx_three_maxima(const int32_t *sizes, int L, int *ind1, int *ind2, int *ind3);
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:570-712; caller src/Tracking.cc:950-962).
+ * F1 = (k1, d1, n1), F2 = (k2, d2, n2), bounds4 = {mnMinX, mnMaxX, mnMinY, mnMaxY} of F2,
+ * prev_matched[2*n1] = vbPrevMatched (in/out), matches12[n1] = vnMatches12 (out).  Host buffers. */
+orbx_status orbx_search_for_initialization(orbx_handle *h, const orbx_keypoint *k1, const uint8_t *d1, int n1,
+                                           const orbx_keypoint *k2, const uint8_t *d2, int n2, const float *bounds4,
+                                           float *prev_matched, int window, float nnratio, int check_orientation,
+                                           int32_t *matches12, int *nmatches);
+/* Frame::ComputeStereoMatches (src/Frame.cc:880-1176).  hl / hr are the left / right extractors whose pyramids of
+ * (frame_left, frame_right) are still resident (mvImagePyramid is read at :910,1040,1072,1079); keypoints and
+ * descriptors are host buffers; u_right / depth = mvuRight / mvDepth.  The reference's unchecked row index (F6)
+ * is clamped. */
+orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int frame_left, int frame_right,
+                              const orbx_keypoint *kl, const uint8_t *dl, int nl, const orbx_keypoint *kr,
+                              const uint8_t *dr, int nr, float mb, float mbf, float *u_right, float *depth,
+                              int *nmatches);
+
 /* ---- stream / timing plumbing ------------------------------------------------------------ */
 void *orbx_get_stream(orbx_handle *h);            /* hipStream_t */
 orbx_status orbx_set_stream(orbx_handle *h, void *hip_stream); /* NULL restores the private stream */

@@ -92,6 +92,21 @@ void orc_match_bruteforce(const uint8_t *q, int nq, const uint8_t *t, int nt,
                           int *best_idx, int *best_dist, int *second_dist);
 void orc_three_maxima(const int *hist_sizes, int L, int *ind1, int *ind2, int *ind3);
 
+/* Frame grid (64 x 48 buckets): AssignFeaturesToGrid / GetFeaturesInArea */
+typedef struct orc_grid orc_grid;
+orc_grid *orc_grid_build(const orc_keypoint *kps, int n, float minx, float maxx, float miny, float maxy);
+void orc_grid_free(orc_grid *g);
+int orc_grid_query(const orc_grid *g, float x, float y, float r, int minLevel, int maxLevel, int *out, int cap);
+/* ORBmatcher::SearchForInitialization; prev_matched[2*n1] in/out, matches12[n1] out; returns nmatches */
+int orc_search_for_initialization(const orc_keypoint *k1, const uint8_t *d1, int n1, const orc_keypoint *k2,
+                                  const uint8_t *d2, int n2, float minx, float maxx, float miny, float maxy,
+                                  float *prev_matched, int window, float nnratio, int check_ori, int *matches12);
+/* Frame::ComputeStereoMatches; returns the number of stereo matches kept */
+int orc_stereo_matches(const orc_keypoint *kL, const uint8_t *dL, int nL, const orc_keypoint *kR, const uint8_t *dR,
+                       int nR, int nlevels, const float *scale, const float *inv_scale, const uint8_t *const *pyrL,
+                       const uint8_t *const *pyrR, const int *pw, const int *ph, float mb, float mbf, float *uRight,
+                       float *depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,19 @@ def lib():
         L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_match_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_three_maxima.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p]
+        L.orc_grid_build.restype = C.c_void_p
+        L.orc_grid_build.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.orc_grid_free.argtypes = [C.c_void_p]
+        L.orc_grid_query.restype = C.c_int
+        L.orc_grid_query.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_search_for_initialization.restype = C.c_int
+        L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int,
+                                                    C.c_float, C.c_int, C.c_void_p]
+        L.orc_stereo_matches.restype = C.c_int
+        L.orc_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -188,3 +201,38 @@ def three_maxima(sizes):
     a, b, c = C.c_int(), C.c_int(), C.c_int()
     lib().orc_three_maxima(_p(sizes), len(sizes), C.byref(a), C.byref(b), C.byref(c))
     return a.value, b.value, c.value
+
+
+def grid_query(kps, bounds, x, y, r, min_level=-1, max_level=-1):
+    """Frame::GetFeaturesInArea over a freshly assigned 64x48 grid; bounds = (minx, maxx, miny, maxy)"""
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    g = lib().orc_grid_build(_p(kps), len(kps), *[float(b) for b in bounds])
+    out = np.zeros(max(len(kps), 1), np.int32)
+    n = lib().orc_grid_query(g, x, y, r, min_level, max_level, _p(out), len(out))
+    lib().orc_grid_free(g)
+    return out[:n].copy()
+
+
+def search_for_initialization(k1, d1, k2, d2, bounds, prev_matched, window=100, nnratio=0.9, check_ori=True):
+    k1 = np.ascontiguousarray(k1, KP_DTYPE); k2 = np.ascontiguousarray(k2, KP_DTYPE)
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.zeros(max(len(k1), 1), np.int32)
+    n = lib().orc_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2),
+                                            *[float(b) for b in bounds], _p(pm), window, nnratio, int(check_ori), _p(m12))
+    return n, m12[:len(k1)].copy(), pm
+
+
+def stereo_matches(kL, dL, kR, dR, scale, inv_scale, pyrL, pyrR, mb, mbf):
+    """pyrL / pyrR: lists of contiguous padded level images (uint8 2-D arrays)"""
+    kL = np.ascontiguousarray(kL, KP_DTYPE); kR = np.ascontiguousarray(kR, KP_DTYPE)
+    dL = np.ascontiguousarray(dL, np.uint8); dR = np.ascontiguousarray(dR, np.uint8)
+    nl = len(pyrL)
+    pyrL = [np.ascontiguousarray(a) for a in pyrL]; pyrR = [np.ascontiguousarray(a) for a in pyrR]
+    PL = (C.c_void_p * nl)(*[a.ctypes.data for a in pyrL]); PR = (C.c_void_p * nl)(*[a.ctypes.data for a in pyrR])
+    pw = np.array([a.shape[1] for a in pyrL], np.int32); ph = np.array([a.shape[0] for a in pyrL], np.int32)
+    sc = np.ascontiguousarray(scale, np.float32); isc = np.ascontiguousarray(inv_scale, np.float32)
+    uR = np.zeros(max(len(kL), 1), np.float32); dep = np.zeros(max(len(kL), 1), np.float32)
+    n = lib().orc_stereo_matches(_p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), nl, _p(sc), _p(isc), PL, PR, _p(pw),
+                                 _p(ph), mb, mbf, _p(uR), _p(dep))
+    return n, uR[:len(kL)].copy(), dep[:len(kL)].copy()

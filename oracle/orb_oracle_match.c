@@ -1,2 +1,286 @@
-/* placeholder TU: matcher policies (SearchForInitialization, ComputeStereoMatches) are added here. */
+/* orb_oracle_match.c -- CPU restatement of the matcher policies on the hot path (see orb_oracle.h).
+ * TEST INFRASTRUCTURE ONLY.
+ *
+ *   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea   src/Frame.cc:432-460, 729-745, 633-717
+ *   ORBmatcher::SearchForInitialization                           src/ORBmatcher.cc:570-712
+ *   Frame::ComputeStereoMatches                                   src/Frame.cc:880-1176
+ *
+ * The Frame / KeyFrame / MapPoint classes cannot be linked here (they need OpenCV, Eigen, DBoW2, g2o), so the
+ * functions take the fields they read as plain arrays.  Fork deviations are followed:
+ * `factor = HISTO_LENGTH / 360.0f`, `iniu = scaleduR0 - L - w`.
+ */
+#define _GNU_SOURCE
 #include "orb_oracle.h"
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FRAME_GRID_ROWS 48 /* include/Frame.h:54 */
+#define FRAME_GRID_COLS 64 /* include/Frame.h:59 */
+#define TH_HIGH 100
+#define TH_LOW 50
+#define HISTO_LENGTH 30
+
+/* ------------------------------------------------------------------ grid */
+struct orc_grid {
+    float minx, miny, winv, hinv;
+    int n;
+    const orc_keypoint *kps;
+    int *cell_begin; /* [COLS*ROWS+1] */
+    int *items;      /* feature indices, cell-major, insertion order */
+};
+
+/* Frame::AssignFeaturesToGrid src/Frame.cc:432-460 with PosInGrid :729-745 */
+orc_grid *orc_grid_build(const orc_keypoint *kps, int n, float minx, float maxx, float miny, float maxy) {
+    orc_grid *g = (orc_grid *)calloc(1, sizeof(*g));
+    g->minx = minx; g->miny = miny;
+    g->winv = (float)FRAME_GRID_COLS / (maxx - minx); /* src/Frame.cc:405-407 */
+    g->hinv = (float)FRAME_GRID_ROWS / (maxy - miny);
+    g->n = n; g->kps = kps;
+    const int nc = FRAME_GRID_COLS * FRAME_GRID_ROWS;
+    int *cell = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    g->cell_begin = (int *)calloc(nc + 1, sizeof(int));
+    g->items = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) {
+        int px = (int)roundf((kps[i].x - minx) * g->winv);
+        int py = (int)roundf((kps[i].y - miny) * g->hinv);
+        if (px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS) cell[i] = -1;
+        else { cell[i] = px * FRAME_GRID_ROWS + py; g->cell_begin[cell[i] + 1]++; }
+    }
+    for (int c = 0; c < nc; ++c) g->cell_begin[c + 1] += g->cell_begin[c];
+    int *fill = (int *)calloc(nc, sizeof(int));
+    for (int i = 0; i < n; ++i)
+        if (cell[i] >= 0) g->items[g->cell_begin[cell[i]] + fill[cell[i]]++] = i;
+    free(fill); free(cell);
+    return g;
+}
+void orc_grid_free(orc_grid *g) {
+    if (!g) return;
+    free(g->cell_begin); free(g->items); free(g);
+}
+
+/* Frame::GetFeaturesInArea src/Frame.cc:633-717 (including the bCheckLevels quirk :673) */
+int orc_grid_query(const orc_grid *g, float x, float y, float r, int minLevel, int maxLevel, int *out, int cap) {
+    int n = 0;
+    int nMinCellX = (int)floorf((x - g->minx - r) * g->winv);
+    if (nMinCellX < 0) nMinCellX = 0;
+    if (nMinCellX >= FRAME_GRID_COLS) return 0;
+    int nMaxCellX = (int)ceilf((x - g->minx + r) * g->winv);
+    if (nMaxCellX > FRAME_GRID_COLS - 1) nMaxCellX = FRAME_GRID_COLS - 1;
+    if (nMaxCellX < 0) return 0;
+    int nMinCellY = (int)floorf((y - g->miny - r) * g->hinv);
+    if (nMinCellY < 0) nMinCellY = 0;
+    if (nMinCellY >= FRAME_GRID_ROWS) return 0;
+    int nMaxCellY = (int)ceilf((y - g->miny + r) * g->hinv);
+    if (nMaxCellY > FRAME_GRID_ROWS - 1) nMaxCellY = FRAME_GRID_ROWS - 1;
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * FRAME_GRID_ROWS + iy;
+            for (int j = g->cell_begin[c]; j < g->cell_begin[c + 1]; ++j) {
+                const orc_keypoint *kp = &g->kps[g->items[j]];
+                if (bCheckLevels) {
+                    if (kp->octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp->octave > maxLevel) continue;
+                }
+                const float distx = kp->x - x, disty = kp->y - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) {
+                    if (n < cap) out[n] = g->items[j];
+                    ++n;
+                }
+            }
+        }
+    return n;
+}
+
+/* ------------------------------------------------------------------ SearchForInitialization */
+/* src/ORBmatcher.cc:570-712.  prev_matched[2*n1] is vbPrevMatched (in/out), matches12[n1] out. */
+int orc_search_for_initialization(const orc_keypoint *k1, const uint8_t *d1, int n1, const orc_keypoint *k2,
+                                  const uint8_t *d2, int n2, float minx, float maxx, float miny, float maxy,
+                                  float *prev_matched, int window, float nnratio, int check_ori, int *matches12) {
+    int nmatches = 0;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    int *hist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (n1 > 0 ? n1 : 1));
+    int hn[HISTO_LENGTH] = {0};
+    const float factor = HISTO_LENGTH / 360.0f; /* fork: src/ORBmatcher.cc:583 */
+    int *matchedDist = (int *)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    int *matches21 = (int *)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    int *cands = (int *)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    for (int i = 0; i < n2; ++i) { matchedDist[i] = INT_MAX; matches21[i] = -1; }
+    orc_grid *g = orc_grid_build(k2, n2, minx, maxx, miny, maxy);
+    for (int i1 = 0; i1 < n1; ++i1) {
+        const int level1 = k1[i1].octave;
+        if (level1 > 0) continue;
+        const int nc = orc_grid_query(g, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window, level1, level1, cands, n2);
+        if (nc == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int i2 = cands[c];
+            const int dist = orc_descriptor_distance(d1 + (size_t)i1 * 32, d2 + (size_t)i2 * 32);
+            if (matchedDist[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2;
+                matches21[bestIdx2] = i1;
+                matchedDist[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_ori) {
+                    float rot = k1[i1].angle - k2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    hist[bin * n1 + hn[bin]++] = i1;
+                }
+            }
+        }
+    }
+    if (check_ori) {
+        int ind1, ind2, ind3;
+        orc_three_maxima(hn, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < hn[i]; j++) {
+                const int idx1 = hist[i * n1 + j];
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; ++i1)
+        if (matches12[i1] >= 0) {
+            prev_matched[2 * i1] = k2[matches12[i1]].x;
+            prev_matched[2 * i1 + 1] = k2[matches12[i1]].y;
+        }
+    orc_grid_free(g);
+    free(hist); free(matchedDist); free(matches21); free(cands);
+    return nmatches;
+}
+
+/* ------------------------------------------------------------------ ComputeStereoMatches */
+typedef struct { int dist, idx; } distidx;
+static int distidx_cmp(const void *a, const void *b) {
+    const distidx *x = (const distidx *)a, *y = (const distidx *)b;
+    if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+/* src/Frame.cc:880-1176.  pyrL/pyrR: the padded pyramid levels of the two extractors (fork: mvImagePyramid holds
+ * the padded images), pw/ph their sizes (row stride = pw).  F6: the reference indexes vRowIndices[yi] without a
+ * bound check (rows reach past mvImagePyramid[0].rows in fork mode) -- the restatement clamps, which is identical
+ * wherever the reference is well-defined.  An empty vDistIdx (reference: undefined behaviour) returns 0 matches. */
+int orc_stereo_matches(const orc_keypoint *kL, const uint8_t *dL, int nL, const orc_keypoint *kR, const uint8_t *dR,
+                       int nR, int nlevels, const float *scale, const float *inv_scale, const uint8_t *const *pyrL,
+                       const uint8_t *const *pyrR, const int *pw, const int *ph, float mb, float mbf, float *uRight,
+                       float *depth) {
+    for (int i = 0; i < nL; ++i) { uRight[i] = -1.0f; depth[i] = -1.0f; }
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = ph[0];
+    /* row table: lists of right keypoints per image row, in ascending iR order */
+    int *rcount = (int *)calloc(nRows + 1, sizeof(int));
+    for (int iR = 0; iR < nR; ++iR) {
+        const float kpY = kR[iR].y;
+        const float r = 2.0f * scale[kR[iR].octave];
+        const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+        for (int yi = minr; yi <= maxr; ++yi)
+            if (yi >= 0 && yi < nRows) rcount[yi + 1]++;
+    }
+    for (int y = 0; y < nRows; ++y) rcount[y + 1] += rcount[y];
+    int *ritems = (int *)malloc(sizeof(int) * (rcount[nRows] > 0 ? rcount[nRows] : 1));
+    int *rfill = (int *)calloc(nRows, sizeof(int));
+    for (int iR = 0; iR < nR; ++iR) {
+        const float kpY = kR[iR].y;
+        const float r = 2.0f * scale[kR[iR].octave];
+        const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+        for (int yi = minr; yi <= maxr; ++yi)
+            if (yi >= 0 && yi < nRows) ritems[rcount[yi] + rfill[yi]++] = iR;
+    }
+    free(rfill);
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    distidx *vDistIdx = (distidx *)malloc(sizeof(distidx) * (nL > 0 ? nL : 1));
+    int nd = 0;
+    for (int iL = 0; iL < nL; ++iL) {
+        const orc_keypoint *kpL = &kL[iL];
+        const int levelL = kpL->octave;
+        const float vL = kpL->y, uL = kpL->x;
+        const long row = (long)vL;
+        if (row < 0 || row >= nRows) continue; /* F6 clamp */
+        const int cb = rcount[row], ce = rcount[row + 1];
+        if (cb == ce) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH;
+        int bestIdxR = 0;
+        for (int c = cb; c < ce; ++c) {
+            const int iR = ritems[c];
+            const orc_keypoint *kpR = &kR[iR];
+            if (kpR->octave < levelL - 1 || kpR->octave > levelL + 1) continue;
+            const float uR = kpR->x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orc_descriptor_distance(dL + (size_t)iL * 32, dR + (size_t)iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = kR[bestIdxR].x;
+            const float scaleFactor = inv_scale[kpL->octave];
+            const float scaleduL = roundf(kpL->x * scaleFactor);
+            const float scaledvL = roundf(kpL->y * scaleFactor);
+            const float scaleduR0 = roundf(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            const int lv = kpL->octave;
+            const int W = pw[lv], H = ph[lv];
+            const int y0 = (int)(scaledvL - w), x0 = (int)(scaleduL - w);
+            /* cv::Mat::rowRange/colRange would assert outside the image: treated as "no match" */
+            if (y0 < 0 || y0 + 2 * w + 1 > H || x0 < 0 || x0 + 2 * w + 1 > W) continue;
+            const uint8_t *IL = pyrL[lv] + (size_t)y0 * W + x0;
+            const float cL = (float)IL[w * W + w];
+            int bestDistS = INT_MAX, bestincR = 0;
+            float vDists[2 * 5 + 1];
+            const float iniu = scaleduR0 - L - w; /* fork: minus (src/Frame.cc:1067) */
+            const float endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= W) continue;
+            for (int incR = -L; incR <= +L; incR++) {
+                const uint8_t *IR = pyrR[lv] + (size_t)y0 * W + ((int)scaleduR0 + incR - w);
+                const float cR = (float)IR[w * W + w];
+                double acc = 0; /* cv::norm(NORM_L1) accumulates in double; operands are integer valued => exact */
+                for (int yy = 0; yy < 2 * w + 1; ++yy)
+                    for (int xx = 0; xx < 2 * w + 1; ++xx) {
+                        const float a = (float)IL[yy * W + xx] - cL, b = (float)IR[yy * W + xx] - cR;
+                        acc += fabsf(a - b);
+                    }
+                const float dist = (float)acc;
+                if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = scale[kpL->octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+                depth[iL] = mbf / disparity;
+                uRight[iL] = bestuR;
+                vDistIdx[nd].dist = bestDistS; vDistIdx[nd].idx = iL; nd++;
+            }
+        }
+    }
+    int nmatch = nd;
+    if (nd > 0) {
+        qsort(vDistIdx, nd, sizeof(distidx), distidx_cmp);
+        const float median = (float)vDistIdx[nd / 2].dist;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nd - 1; i >= 0; i--) {
+            if (vDistIdx[i].dist < thDist) break;
+            uRight[vDistIdx[i].idx] = -1; depth[vDistIdx[i].idx] = -1; nmatch--;
+        }
+    }
+    free(vDistIdx); free(rcount); free(ritems);
+    return nmatch;
+}

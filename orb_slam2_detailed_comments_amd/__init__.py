@@ -6,3 +6,4 @@ inputs.  All compute is in csrc/ (hand-written HIP for gfx950).  There is no CPU
 from ._capi import KP_DTYPE, OrbxError, LIB_PATH  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import ORBmatcher  # noqa: F401
+from .frame import Frame  # noqa: F401

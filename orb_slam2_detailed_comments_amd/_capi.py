@@ -41,6 +41,8 @@ SYMBOLS = [
     "orbx_pyramid_level_copy", "orbx_match_bruteforce_device", "orbx_match_bruteforce", "orbx_hamming_matrix",
     "orbx_get_stream", "orbx_set_stream", "orbx_synchronize", "orbx_profile_enable", "orbx_profile_read",
     "orbx_kernel_name", "orbx_debug_candidates", "orbx_debug_level_keypoints", "orbx_debug_blur_copy",
+    "orbx_grid_create", "orbx_grid_destroy", "orbx_grid_query", "orbx_three_maxima",
+    "orbx_search_for_initialization", "orbx_stereo_match",
 ]
 
 _lib = None
@@ -90,6 +92,15 @@ def lib():
     L.orbx_debug_level_keypoints.restype = i32
     L.orbx_debug_level_keypoints.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
     L.orbx_debug_blur_copy.restype = i32; L.orbx_debug_blur_copy.argtypes = [vp, i32, i32, vp, i32]
+    L.orbx_grid_create.restype = vp; L.orbx_grid_create.argtypes = [vp, i32, f32, f32, f32, f32]
+    L.orbx_grid_destroy.restype = None; L.orbx_grid_destroy.argtypes = [vp]
+    L.orbx_grid_query.restype = i32; L.orbx_grid_query.argtypes = [vp, f32, f32, f32, i32, i32, vp, i32]
+    L.orbx_three_maxima.restype = None
+    L.orbx_three_maxima.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.orbx_search_for_initialization.restype = i32
+    L.orbx_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, i32, vp, C.POINTER(i32)]
+    L.orbx_stereo_match.restype = i32
+    L.orbx_stereo_match.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
     _lib = L
     return L
 

@@ -587,3 +587,239 @@ extern "C" orbx_status orbx_profile_read(orbx_handle *h, float *ms, int32_t *lau
     if (reset) { memset(h->ms, 0, sizeof(h->ms)); memset(h->launches, 0, sizeof(h->launches)); }
     return ORBX_OK;
 }
+
+// ================================================================ matcher policies on the path (a13, a16, a17)
+// The Hamming work runs on the GPU; the order-dependent bookkeeping of each policy is host code, as the
+// reference's own structure dictates.
+#include <cmath>
+#include <climits>
+
+// ---------------------------------------------------------------- a17: Frame grid (src/Frame.cc:432-460, 633-745)
+struct orbx_grid {
+    static const int COLS = 64, ROWS = 48;     // FRAME_GRID_COLS / FRAME_GRID_ROWS (include/Frame.h:54,59)
+    float minx, miny, winv, hinv;
+    const orbx_keypoint *kps;
+    std::vector<int> begin, items;
+};
+
+extern "C" orbx_grid *orbx_grid_create(const orbx_keypoint *kps, int n, float min_x, float max_x, float min_y, float max_y) {
+    if (n < 0 || (n > 0 && !kps) || !(max_x > min_x) || !(max_y > min_y)) { g_last_error = "bad grid arguments"; return nullptr; }
+    orbx_grid *g = new orbx_grid();
+    g->minx = min_x; g->miny = min_y; g->kps = kps;
+    g->winv = (float)orbx_grid::COLS / (max_x - min_x);
+    g->hinv = (float)orbx_grid::ROWS / (max_y - min_y);
+    const int nc = orbx_grid::COLS * orbx_grid::ROWS;
+    std::vector<int> cell(n);
+    g->begin.assign(nc + 1, 0);
+    for (int i = 0; i < n; ++i) {                     // PosInGrid: C round(), then the range test
+        const int px = (int)roundf((kps[i].x - min_x) * g->winv), py = (int)roundf((kps[i].y - min_y) * g->hinv);
+        cell[i] = (px < 0 || px >= orbx_grid::COLS || py < 0 || py >= orbx_grid::ROWS) ? -1 : px * orbx_grid::ROWS + py;
+        if (cell[i] >= 0) g->begin[cell[i] + 1]++;
+    }
+    for (int c = 0; c < nc; ++c) g->begin[c + 1] += g->begin[c];
+    g->items.resize(n);
+    std::vector<int> fill(nc, 0);
+    for (int i = 0; i < n; ++i)
+        if (cell[i] >= 0) g->items[g->begin[cell[i]] + fill[cell[i]]++] = i;   // push_back order = feature order
+    return g;
+}
+extern "C" void orbx_grid_destroy(orbx_grid *g) { delete g; }
+
+// GetFeaturesInArea: same cell walk (x outer, y inner), same level filter quirk (`minLevel > 0 || maxLevel >= 0`)
+extern "C" int orbx_grid_query(const orbx_grid *g, float x, float y, float r, int min_level, int max_level, int32_t *out,
+                               int cap) {
+    if (!g) return -1;
+    int x0 = std::max(0, (int)floorf((x - g->minx - r) * g->winv));
+    if (x0 >= orbx_grid::COLS) return 0;
+    int x1 = std::min(orbx_grid::COLS - 1, (int)ceilf((x - g->minx + r) * g->winv));
+    if (x1 < 0) return 0;
+    int y0 = std::max(0, (int)floorf((y - g->miny - r) * g->hinv));
+    if (y0 >= orbx_grid::ROWS) return 0;
+    int y1 = std::min(orbx_grid::ROWS - 1, (int)ceilf((y - g->miny + r) * g->hinv));
+    if (y1 < 0) return 0;
+    const bool check = (min_level > 0) || (max_level >= 0);
+    int n = 0;
+    for (int ix = x0; ix <= x1; ++ix)
+        for (int iy = y0; iy <= y1; ++iy) {
+            const int c = ix * orbx_grid::ROWS + iy;
+            for (int j = g->begin[c]; j < g->begin[c + 1]; ++j) {
+                const orbx_keypoint &kp = g->kps[g->items[j]];
+                if (check) {
+                    if (kp.octave < min_level) continue;
+                    if (max_level >= 0 && kp.octave > max_level) continue;
+                }
+                if (fabsf(kp.x - x) < r && fabsf(kp.y - y) < r) {
+                    if (n < cap && out) out[n] = g->items[j];
+                    ++n;
+                }
+            }
+        }
+    return n;
+}
+
+// ---------------------------------------------------------------- a15: ComputeThreeMaxima (src/ORBmatcher.cc:2026-2068)
+extern "C" void orbx_three_maxima(const int32_t *sizes, int L, int *ind1, int *ind2, int *ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    *ind1 = *ind2 = *ind3 = -1;
+    for (int i = 0; i < L; ++i) {
+        const int s = sizes[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > max3) { max3 = s; *ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+// ---------------------------------------------------------------- a13: SearchForInitialization (src/ORBmatcher.cc:570-712)
+// GPU: one Hamming matrix between the level-0 features of both frames (the only ones the policy can pair:
+// `if (level1 > 0) continue` and GetFeaturesInArea(..., level1, level1)).  Host: the sequential selection pass.
+extern "C" orbx_status orbx_search_for_initialization(orbx_handle *h, const orbx_keypoint *k1, const uint8_t *d1, int n1,
+                                                      const orbx_keypoint *k2, const uint8_t *d2, int n2,
+                                                      const float *bounds4, float *prev_matched, int window,
+                                                      float nnratio, int check_orientation, int32_t *matches12,
+                                                      int *nmatches_out) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (n1 < 0 || n2 < 0 || !bounds4 || !matches12 || !nmatches_out || (n1 > 0 && (!k1 || !d1 || !prev_matched)) ||
+        (n2 > 0 && (!k2 || !d2)))
+        return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    const int HISTO = 30, TH_LOW_ = 50;
+    *nmatches_out = 0;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return ORBX_OK;
+    // level-0 subsets and the GPU distance matrix between them
+    std::vector<int> l1, l2, pos2(n2, -1);
+    for (int i = 0; i < n1; ++i) if (k1[i].octave <= 0) l1.push_back(i);
+    for (int i = 0; i < n2; ++i) if (k2[i].octave == 0) { pos2[i] = (int)l2.size(); l2.push_back(i); }
+    std::vector<uint16_t> D;
+    std::vector<int> pos1(n1, -1);
+    if (!l1.empty() && !l2.empty()) {
+        std::vector<uint8_t> q(l1.size() * 32), t(l2.size() * 32);
+        for (size_t i = 0; i < l1.size(); ++i) { memcpy(&q[i * 32], d1 + (size_t)l1[i] * 32, 32); pos1[l1[i]] = (int)i; }
+        for (size_t i = 0; i < l2.size(); ++i) memcpy(&t[i * 32], d2 + (size_t)l2[i] * 32, 32);
+        D.resize(l1.size() * l2.size());
+        orbx_status st = orbx_hamming_matrix(h, q.data(), (int)l1.size(), t.data(), (int)l2.size(), D.data());
+        if (st != ORBX_OK) return st;
+    }
+    orbx_grid *grid = orbx_grid_create(k2, n2, bounds4[0], bounds4[1], bounds4[2], bounds4[3]);
+    if (!grid) return fail(ORBX_BAD_ARGUMENT, "bad image bounds");
+    int nmatches = 0;
+    std::vector<std::vector<int>> rotHist(HISTO);
+    const float factor = HISTO / 360.0f;               // fork value (src/ORBmatcher.cc:583)
+    std::vector<int> matchedDist(n2, INT_MAX), matches21(n2, -1), cands(n2);
+    for (int i1 = 0; i1 < n1; ++i1) {
+        const int level1 = k1[i1].octave;
+        if (level1 > 0) continue;
+        const int nc = orbx_grid_query(grid, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window, level1, level1,
+                                       cands.data(), n2);
+        if (nc == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int i2 = cands[c];
+            // level1 == 0 here, or < 0 (never produced by the extractor): candidates then have octave >= level1 only
+            const int dist = (pos1[i1] >= 0 && pos2[i2] >= 0) ? (int)D[(size_t)pos1[i1] * l2.size() + pos2[i2]] : 256 + 1;
+            if (matchedDist[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW_ && (float)bestDist < (float)bestDist2 * nnratio) {
+            if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nmatches--; }
+            matches12[i1] = bestIdx2;
+            matches21[bestIdx2] = i1;
+            matchedDist[bestIdx2] = bestDist;
+            nmatches++;
+            if (check_orientation) {
+                float rot = k1[i1].angle - k2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO) bin = 0;
+                if (bin >= 0 && bin < HISTO) rotHist[bin].push_back(i1);
+            }
+        }
+    }
+    if (check_orientation) {
+        int32_t sizes[30]; int i1, i2, i3;
+        for (int i = 0; i < HISTO; ++i) sizes[i] = (int)rotHist[i].size();
+        orbx_three_maxima(sizes, HISTO, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO; ++i) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int idx1 : rotHist[i])
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < n1; ++i)
+        if (matches12[i] >= 0) { prev_matched[2 * i] = k2[matches12[i]].x; prev_matched[2 * i + 1] = k2[matches12[i]].y; }
+    orbx_grid_destroy(grid);
+    *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------- a16: ComputeStereoMatches (src/Frame.cc:880-1176)
+extern "C" orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int frame_left, int frame_right,
+                                         const orbx_keypoint *kl, const uint8_t *dl, int nl, const orbx_keypoint *kr,
+                                         const uint8_t *dr, int nr, float mb, float mbf, float *u_right, float *depth,
+                                         int *nmatches_out) {
+    if (!hl || !hr || hl->host_only || hr->host_only) return fail(ORBX_BAD_ARGUMENT, "two device handles are required");
+    if (nl < 0 || nr < 0 || nr > 65535 || (nl > 0 && (!kl || !dl || !u_right || !depth)) || (nr > 0 && (!kr || !dr)) ||
+        !(mb > 0.f))
+        return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    orbx_status st = check_level(hl, frame_left, 0);
+    if (st != ORBX_OK) return st;
+    st = check_level(hr, frame_right, 0);
+    if (st != ORBX_OK) return st;
+    if (hl->dev != hr->dev || hl->geom.width != hr->geom.width || hl->geom.height != hr->geom.height ||
+        hl->p.nlevels != hr->p.nlevels || hl->p.scale_factor != hr->p.scale_factor)
+        return fail(ORBX_BAD_ARGUMENT, "left and right extractor must share device, image size and pyramid parameters");
+    if (nmatches_out) *nmatches_out = 0;
+    if (nl == 0) return ORBX_OK;
+    HIPCHK(hipSetDevice(hl->dev));
+    HIPCHK(hipStreamSynchronize(hr->stream));   // the right pyramid is read from the left handle's stream
+    OrbxStereoGeom sg;
+    memset(&sg, 0, sizeof(sg));
+    sg.nlevels = hl->p.nlevels; sg.nrows0 = hl->geom.lv[0].ph; sg.mb = mb; sg.mbf = mbf;
+    for (int l = 0; l < sg.nlevels; ++l) {
+        sg.scale[l] = hl->tab.scale[l]; sg.inv_scale[l] = hl->tab.inv_scale[l];
+        sg.pw[l] = hl->geom.lv[l].pw; sg.ph[l] = hl->geom.lv[l].ph; sg.pitch[l] = hl->geom.lv[l].pitch;
+        sg.off[l] = hl->geom.lv[l].off;
+    }
+    orbx_keypoint *dkl = nullptr, *dkr = nullptr; uint8_t *ddl = nullptr, *ddr = nullptr;
+    float *du = nullptr, *dz = nullptr; int *dsad = nullptr;
+    HIPCHK(hipMalloc(&dkl, (size_t)nl * sizeof(orbx_keypoint)));
+    HIPCHK(hipMalloc(&ddl, (size_t)nl * 32));
+    HIPCHK(hipMalloc(&dkr, (size_t)std::max(nr, 1) * sizeof(orbx_keypoint)));
+    HIPCHK(hipMalloc(&ddr, (size_t)std::max(nr, 1) * 32));
+    HIPCHK(hipMalloc(&du, (size_t)nl * sizeof(float)));
+    HIPCHK(hipMalloc(&dz, (size_t)nl * sizeof(float)));
+    HIPCHK(hipMalloc(&dsad, (size_t)nl * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(dkl, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, hl->stream));
+    HIPCHK(hipMemcpyAsync(ddl, dl, (size_t)nl * 32, hipMemcpyHostToDevice, hl->stream));
+    if (nr > 0) {
+        HIPCHK(hipMemcpyAsync(dkr, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, hl->stream));
+        HIPCHK(hipMemcpyAsync(ddr, dr, (size_t)nr * 32, hipMemcpyHostToDevice, hl->stream));
+    }
+    { ProfScope ps(hl, ORBX_K_MATCH);
+      orbx_launch_stereo(hl->stream, sg, dkl, ddl, nl, dkr, ddr, nr, hl->d_pyr + (size_t)frame_left * hl->geom.pyr_bytes,
+                         hr->d_pyr + (size_t)frame_right * hr->geom.pyr_bytes, du, dz, dsad); }
+    std::vector<int> sad(nl);
+    HIPCHK(hipMemcpyAsync(u_right, du, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, hl->stream));
+    HIPCHK(hipMemcpyAsync(depth, dz, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, hl->stream));
+    HIPCHK(hipMemcpyAsync(sad.data(), dsad, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, hl->stream));
+    hipError_t e = hipStreamSynchronize(hl->stream);
+    hipFree(dkl); hipFree(ddl); hipFree(dkr); hipFree(ddr); hipFree(du); hipFree(dz); hipFree(dsad);
+    if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
+    // median cut (:1160-1175): sort (SAD, index), drop everything at or above 1.5 * 1.4 * median
+    std::vector<std::pair<int, int>> v;
+    for (int i = 0; i < nl; ++i) if (sad[i] >= 0) v.push_back({sad[i], i});
+    int kept = (int)v.size();
+    if (!v.empty()) {
+        std::sort(v.begin(), v.end());
+        const float median = (float)v[v.size() / 2].first;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = (int)v.size() - 1; i >= 0; --i) {
+            if ((float)v[i].first < thDist) break;
+            u_right[v[i].second] = -1; depth[v[i].second] = -1; --kept;
+        }
+    }
+    if (nmatches_out) *nmatches_out = kept;
+    return ORBX_OK;
+}

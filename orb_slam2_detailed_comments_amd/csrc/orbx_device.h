@@ -27,6 +27,15 @@ struct DGeom {
     DLevel lv[ORBX_MAX_LEVELS];
 };
 
+// geometry of the two pyramids ComputeStereoMatches reads (both handles share it: same image size / params)
+struct OrbxStereoGeom {
+    int nlevels, nrows0;
+    float mb, mbf;
+    float scale[ORBX_MAX_LEVELS], inv_scale[ORBX_MAX_LEVELS];
+    int pw[ORBX_MAX_LEVELS], ph[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS];
+    long long off[ORBX_MAX_LEVELS];
+};
+
 #define ORBX_WAVE 64
 
 __device__ __forceinline__ int orbx_reflect101(int i, int n) {

@@ -899,6 +899,106 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t *__restric
                          __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w));
 }
 
+// ------------------------------------------------------------------------------------------------
+// K8: Frame::ComputeStereoMatches (reference src/Frame.cc:880-1176), one wave per LEFT keypoint.
+//  phase A: every lane scans right keypoints (stride 64); the reference's row table (:926-942) is the predicate
+//           floor(yR - r) <= (int)vL <= ceil(yR + r) with r = 2*scale[octaveR]; candidates are visited in ascending
+//           index, so min over key = dist << 16 | iR reproduces the strict '<' bookkeeping (:990-1018).
+//  phase B: 11x11 patch vs 11 shifts, centre-subtracted L1 (:1040-1101) in exact integer arithmetic; the
+//           parabola (:1121-1129) uses the same single-rounded float operations as the reference.
+// The final median cut (:1160-1175) is a sort over <= N integers and stays on the host (orbx_api.cpp).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stereo(OrbxStereoGeom sg, const orbx_keypoint *__restrict__ kL,
+                                                const uint8_t *__restrict__ dL, int nL,
+                                                const orbx_keypoint *__restrict__ kR,
+                                                const uint8_t *__restrict__ dR, int nR,
+                                                const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
+                                                float *__restrict__ uRight, float *__restrict__ depth,
+                                                int *__restrict__ sad) {
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= nL) return;
+    const orbx_keypoint kp = kL[iL];
+    if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; sad[iL] = -1; }
+    const int levelL = kp.octave;
+    const float vL = kp.y, uL = kp.x;
+    const long long row = (long long)vL;
+    if (row < 0 || row >= sg.nrows0) return;                 // F6 clamp (reference: out-of-bounds index)
+    const float maxD = sg.mbf / sg.mb, minD = 0.f;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (maxU < 0) return;
+    const uint4 *qp = (const uint4 *)(dL + (long long)iL * 32);
+    const uint4 qa = qp[0], qb = qp[1];
+    uint32_t best = 0xffffffffu;
+    for (int iR = lane; iR < nR; iR += 64) {
+        const orbx_keypoint kr = kR[iR];
+        const float r = 2.0f * sg.scale[kr.octave];
+        const int maxr = (int)ceilf(kr.y + r), minr = (int)floorf(kr.y - r);
+        const bool cand = (int)(row >= minr) & (int)(row <= maxr) & (int)(kr.octave >= levelL - 1) &
+                          (int)(kr.octave <= levelL + 1) & (int)(kr.x >= minU) & (int)(kr.x <= maxU);
+        if (cand) {
+            const uint4 *tp = (const uint4 *)(dR + (long long)iR * 32);
+            const uint4 ta = tp[0], tb = tp[1];
+            const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                               __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+            if (d < 100u) best = min(best, (d << 16) | (uint32_t)iR);   // bestDist starts at TH_HIGH, strict '<'
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 64));
+    if (best == 0xffffffffu || (best >> 16) >= 75u) return;  // thOrbDist = (TH_HIGH + TH_LOW) / 2
+    const int bestIdxR = (int)(best & 0xffffu);
+    const float uR0 = kR[bestIdxR].x;
+    const float scaleFactor = sg.inv_scale[levelL];
+    const float scaleduL = roundf(kp.x * scaleFactor), scaledvL = roundf(kp.y * scaleFactor);
+    const float scaleduR0 = roundf(uR0 * scaleFactor);
+    const int w = 5, Lh = 5;
+    const int W = sg.pw[levelL], H = sg.ph[levelL], pitch = sg.pitch[levelL];
+    const int y0 = (int)(scaledvL - w), x0 = (int)(scaleduL - w);
+    if (y0 < 0 || y0 + 2 * w + 1 > H || x0 < 0 || x0 + 2 * w + 1 > W) return;
+    const float iniu = scaleduR0 - Lh - w, endu = scaleduR0 + Lh + w + 1;   // fork: minus (src/Frame.cc:1067)
+    if (iniu < 0 || endu >= W) return;
+    const uint8_t *IL = pyrL + sg.off[levelL] + (long long)y0 * pitch + x0;
+    const uint8_t *IR = pyrR + sg.off[levelL] + (long long)y0 * pitch + ((int)scaleduR0 - w);
+    const int cL = IL[w * pitch + w];
+    int acc[11];
+#pragma unroll
+    for (int s = 0; s < 11; ++s) acc[s] = 0;
+    for (int p = lane; p < 121; p += 64) {
+        const int yy = p / 11, xx = p - yy * 11;
+        const int a = (int)IL[yy * pitch + xx] - cL;
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            const int inc = s - Lh;
+            const int cR = IR[w * pitch + w + inc];
+            const int b = (int)IR[yy * pitch + xx + inc] - cR;
+            acc[s] += abs(a - b);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 11; ++s) acc[s] = orbx_wave_sum(acc[s]);
+    if (lane != 0) return;
+    int bestDistS = 0x7fffffff, bestinc = 0;
+#pragma unroll
+    for (int s = 0; s < 11; ++s)
+        if (acc[s] < bestDistS) { bestDistS = acc[s]; bestinc = s - Lh; }
+    if (bestinc == -Lh || bestinc == Lh) return;
+    float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
+#pragma unroll
+    for (int s = 1; s < 10; ++s)
+        if (s - Lh == bestinc) { dist1 = (float)acc[s - 1]; dist2 = (float)acc[s]; dist3 = (float)acc[s + 1]; }
+    const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+    if (deltaR < -1 || deltaR > 1) return;
+    float bestuR = sg.scale[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
+    float disparity = uL - bestuR;
+    if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) { disparity = (float)0.01; bestuR = (float)((double)uL - 0.01); }
+        depth[iL] = sg.mbf / disparity;
+        uRight[iL] = bestuR;
+        sad[iL] = bestDistS;
+    }
+}
+
 // small helper: zero per-batch counters / status
 __global__ void k_clear(int *a, int na, int *b, int nb, int *c, int nc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -983,4 +1083,12 @@ void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const u
     const long long n = (long long)nq * nt;
     if (n <= 0) return;
     hipLaunchKernelGGL(k_hamming_matrix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q, nq, t, nt, dist);
+}
+
+void orbx_launch_stereo(hipStream_t s, const OrbxStereoGeom &sg, const orbx_keypoint *kL, const uint8_t *dL, int nL,
+                        const orbx_keypoint *kR, const uint8_t *dR, int nR, const uint8_t *pyrL, const uint8_t *pyrR,
+                        float *uRight, float *depth, int *sad) {
+    if (nL <= 0) return;
+    hipLaunchKernelGGL(k_stereo, dim3((nL + 3) / 4), dim3(256), 0, s, sg, kL, dL, nL, kR, dR, nR, pyrL, pyrR, uRight,
+                       depth, sad);
 }

@@ -47,6 +47,22 @@ class ORBmatcher:
         ok = (bd <= th) & (bd.astype(np.float32) < sd.astype(np.float32) * self.mfNNratio)
         return np.where(ok, bi, -1).astype(np.int32)
 
+    # ---- SearchForInitialization (src/ORBmatcher.cc:570-712; caller src/Tracking.cc:950-962)
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10):
+        """F1, F2: frame.Frame; vbPrevMatched: [N1,2] float32, updated in place.  Returns (nmatches, vnMatches12)."""
+        import ctypes as C
+        pm = np.ascontiguousarray(vbPrevMatched, np.float32)
+        m12 = np.full(max(F1.N, 1), -1, np.int32)
+        bounds = np.asarray(F2.bounds, np.float32)
+        n = C.c_int(0)
+        check(self._L.orbx_search_for_initialization(
+            self._ex.handle, ptr(F1.mvKeysUn), ptr(F1.mDescriptors), F1.N, ptr(F2.mvKeysUn), ptr(F2.mDescriptors), F2.N,
+            ptr(bounds), ptr(pm), int(windowSize), float(self.mfNNratio), int(self.mbCheckOrientation), ptr(m12),
+            C.byref(n)))
+        if pm is not vbPrevMatched:
+            vbPrevMatched[...] = pm
+        return n.value, m12[:F1.N].copy()
+
     # ---- ComputeThreeMaxima (src/ORBmatcher.cc:2026-2068): 30 numbers, host side
     @staticmethod
     def ComputeThreeMaxima(sizes):
