@@ -52,6 +52,7 @@ struct orbx_handle {
     orbx_keypoint *d_kps = nullptr; uint8_t *d_desc = nullptr; int *d_counts = nullptr; int *d_ustatus = nullptr;
     int out_cap = 0;
     int last_batch = 0;
+    int mk_w = 0, mk_h = 0, mk_total = 0;   // orbx_max_keypoints cache
     // profiling
     uint32_t prof_mask = 0;
     std::vector<ProfPair> pending;
@@ -275,9 +276,12 @@ extern "C" orbx_status orbx_get_umax(const orbx_handle *h, int32_t *umax16) {
 }
 extern "C" int orbx_max_keypoints(orbx_handle *h, int width, int height) {
     if (!h || width <= 0 || height <= 0) return -(int)ORBX_BAD_ARGUMENT;
+    if (h->configured && h->geom.width == width && h->geom.height == height) return h->geom.kp_total;
+    if (h->mk_w == width && h->mk_h == height) return h->mk_total;
     OrbxGeom g; const char *why = "";
     const orbx_status st = orbx_build_geometry(h->p, h->tab, width, height, g, &why);
     if (st != ORBX_OK) { g_last_error = why; return -(int)st; }
+    h->mk_w = width; h->mk_h = height; h->mk_total = g.kp_total;
     return g.kp_total;
 }
 
