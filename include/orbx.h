@@ -151,6 +151,33 @@ orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int frame_left, 
                               const uint8_t *dr, int nr, float mb, float mbf, float *u_right, float *depth,
                               int *nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (src/ORBmatcher.cc:1702-1871;
+ * caller Tracking::TrackWithMotionModel, src/Tracking.cc:1430,1445).  The Frame / MapPoint fields the policy reads are
+ * passed as arrays.  CurrentFrame.mvpMapPoints is all-NULL on entry (src/Tracking.cc:1420 fills it); the result is
+ * matched_last[i2] = index of the last-frame feature whose MapPoint was assigned to current feature i2, or -1. */
+typedef struct orbx_frame_view {
+    const orbx_keypoint *keys_un;   /* mvKeysUn */
+    const uint8_t *desc;            /* mDescriptors, n x 32 */
+    const float *u_right;           /* mvuRight (-1 for monocular points) */
+    int32_t n;
+    float Tcw[16];                  /* mTcw, row major 4x4 */
+    float fx, fy, cx, cy;
+    float min_x, max_x, min_y, max_y; /* mnMinX .. mnMaxY */
+    float mb, mbf;
+} orbx_frame_view;
+typedef struct orbx_last_frame_view {
+    const orbx_keypoint *keys_un;   /* LastFrame.mvKeysUn (octave, angle) */
+    int32_t n;
+    const uint8_t *has_map_point;   /* mvpMapPoints[i] != NULL && !mvbOutlier[i] */
+    const float *world_pos;         /* pMP->GetWorldPos(), 3 floats per feature */
+    const uint8_t *mp_desc;         /* pMP->GetDescriptor(), 32 bytes per feature */
+    const int32_t *observations;    /* pMP->Observations() */
+    float Tcw[16];                  /* LastFrame.mTcw */
+} orbx_last_frame_view;
+orbx_status orbx_search_by_projection_frame(orbx_handle *h, const orbx_frame_view *cur, const orbx_last_frame_view *last,
+                                            float th, int mono, int check_orientation, int32_t *matched_last,
+                                            int *nmatches);
+
 /* ---- stream / timing plumbing ------------------------------------------------------------ */
 void *orbx_get_stream(orbx_handle *h);            /* hipStream_t */
 orbx_status orbx_set_stream(orbx_handle *h, void *hip_stream); /* NULL restores the private stream */

@@ -106,6 +106,13 @@ int orc_stereo_matches(const orc_keypoint *kL, const uint8_t *dL, int nL, const 
                        int nR, int nlevels, const float *scale, const float *inv_scale, const uint8_t *const *pyrL,
                        const uint8_t *const *pyrR, const int *pw, const int *ph, float mb, float mbf, float *uRight,
                        float *depth);
+/* ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono); matched_last[nc] out; returns nmatches */
+int orc_search_by_projection_ff(const orc_keypoint *kc, const uint8_t *dc, const float *u_right, int nc,
+                                const float *Tcw, float fx, float fy, float cx, float cy, float minx, float maxx,
+                                float miny, float maxy, float mb, float mbf, const float *scale_factors,
+                                const orc_keypoint *kl, int nl, const uint8_t *has_mp, const float *xw,
+                                const uint8_t *mpdesc, const int *obs, const float *Tlw, float th, int bMono,
+                                int check_ori, int fp_mode, int *matched_last);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,10 @@ def lib():
         L.orc_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_search_by_projection_ff.restype = C.c_int
+        L.orc_search_by_projection_ff.argtypes = ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_float] * 10 +
+                                                  [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p])
         _LIB = L
     return _LIB
 
@@ -236,3 +240,18 @@ def stereo_matches(kL, dL, kR, dR, scale, inv_scale, pyrL, pyrR, mb, mbf):
     n = lib().orc_stereo_matches(_p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), nl, _p(sc), _p(isc), PL, PR, _p(pw),
                                  _p(ph), mb, mbf, _p(uR), _p(dep))
     return n, uR[:len(kL)].copy(), dep[:len(kL)].copy()
+
+
+def search_by_projection_ff(kc, dc, u_right, Tcw, K, bounds, mb, mbf, scale, kl, has_mp, xw, mpdesc, obs, Tlw, th, mono,
+                            check_ori=True, fp_mode=FP_GCC_FMA):
+    """K = (fx, fy, cx, cy); bounds = (minx, maxx, miny, maxy)"""
+    kc = np.ascontiguousarray(kc, KP_DTYPE); kl = np.ascontiguousarray(kl, KP_DTYPE)
+    arr = lambda a, t: np.ascontiguousarray(a, t)
+    dc, mpdesc = arr(dc, np.uint8), arr(mpdesc, np.uint8)
+    u_right, xw, Tcw, Tlw, scale = (arr(a, np.float32) for a in (u_right, xw, Tcw, Tlw, scale))
+    has_mp, obs = arr(has_mp, np.uint8), arr(obs, np.int32)
+    out = np.full(max(len(kc), 1), -1, np.int32)
+    n = lib().orc_search_by_projection_ff(_p(kc), _p(dc), _p(u_right), len(kc), _p(Tcw), *[float(v) for v in K],
+                                          *[float(b) for b in bounds], mb, mbf, _p(scale), _p(kl), len(kl), _p(has_mp),
+                                          _p(xw), _p(mpdesc), _p(obs), _p(Tlw), th, int(mono), int(check_ori), fp_mode, _p(out))
+    return n, out[:len(kc)].copy()

@@ -284,3 +284,99 @@ int orc_stereo_matches(const orc_keypoint *kL, const uint8_t *dL, int nL, const 
     free(vDistIdx); free(rcount); free(ritems);
     return nmatch;
 }
+
+/* ------------------------------------------------------------------ SearchByProjection(Frame&, const Frame&, th, bMono) */
+/* src/ORBmatcher.cc:1702-1871 (caller src/Tracking.cc:1430,1445).  MapPoint state is passed as arrays:
+ *   last frame : has_mp[i] (pMP && !mvbOutlier[i]), world position xw[3*i], representative descriptor mpdesc[32*i]
+ *                (pMP->GetDescriptor()), obs[i] = pMP->Observations(), keypoints kl (octave, angle of mvKeysUn)
+ *   current    : keypoints kc, descriptors dc, u_right[] (mvuRight), Tcw, intrinsics, bounds; its mvpMapPoints are
+ *                all NULL on entry (Tracking fills them with NULL before the call, src/Tracking.cc:1420) and the
+ *                result is matched_last[i2] = index of the last-frame point assigned to current feature i2, or -1.
+ * OpenCV boundary (parity unpinned): Rcw * x3Dw + tcw is cv::gemm's 3x3 * 3x1 float special case:
+ *   t = a0*b0 + a1*b1 + a2*b2 in float (left to right), result = (float)((double)t + (double)tcw_i).
+ * fp_mode: `fx*xc*invzc + cx` and `u - mbf*invzc` are contracted by g++ -O3 -march=native (reference flags) into
+ *   fma(fx*xc, invzc, cx) and fma(-mbf, invzc, u); STRICT evaluates them with separate roundings. */
+static float gemm3(const float *a, const float *b, float c) {
+    float t = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    return (float)((double)t * 1.0 + (double)c * 1.0);
+}
+
+int orc_search_by_projection_ff(const orc_keypoint *kc, const uint8_t *dc, const float *u_right, int nc,
+                                const float *Tcw /*4x4 row major*/, float fx, float fy, float cx, float cy, float minx,
+                                float maxx, float miny, float maxy, float mb, float mbf, const float *scale_factors,
+                                const orc_keypoint *kl, int nl, const uint8_t *has_mp, const float *xw,
+                                const uint8_t *mpdesc, const int *obs, const float *Tlw, float th, int bMono,
+                                int check_ori, int fp_mode, int *matched_last) {
+    int nmatches = 0;
+    for (int i = 0; i < nc; ++i) matched_last[i] = -1;
+    int *hist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (nl > 0 ? nl : 1));
+    int hn[HISTO_LENGTH] = {0};
+    const float factor = HISTO_LENGTH / 360.0f; /* fork: :1713 */
+    float Rcw[9], tcw[3], Rlw[9], tlw[3], twc[3], tlc[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) { Rcw[3 * r + c] = Tcw[4 * r + c]; Rlw[3 * r + c] = Tlw[4 * r + c]; }
+        tcw[r] = Tcw[4 * r + 3]; tlw[r] = Tlw[4 * r + 3];
+    }
+    for (int r = 0; r < 3; ++r) { /* twc = -Rcw.t() * tcw : gemm with alpha = -1 */
+        float t = Rcw[0 + r] * tcw[0] + Rcw[3 + r] * tcw[1] + Rcw[6 + r] * tcw[2];
+        twc[r] = (float)((double)t * -1.0);
+    }
+    for (int r = 0; r < 3; ++r) tlc[r] = gemm3(&Rlw[3 * r], twc, tlw[r]);
+    const int bForward = tlc[2] > mb && !bMono;
+    const int bBackward = -tlc[2] > mb && !bMono;
+    orc_grid *g = orc_grid_build(kc, nc, minx, maxx, miny, maxy);
+    int *cands = (int *)malloc(sizeof(int) * (nc > 0 ? nc : 1));
+    for (int i = 0; i < nl; i++) {
+        if (!has_mp[i]) continue;
+        float x3Dc[3];
+        for (int r = 0; r < 3; ++r) x3Dc[r] = gemm3(&Rcw[3 * r], &xw[3 * i], tcw[r]);
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / x3Dc[2]);
+        if (invzc < 0) continue;
+        float u, v;
+        if (fp_mode == ORC_FP_GCC_FMA) { u = fmaf(fx * xc, invzc, cx); v = fmaf(fy * yc, invzc, cy); }
+        else { u = fx * xc * invzc + cx; v = fy * yc * invzc + cy; }
+        if (u < minx || u > maxx) continue;
+        if (v < miny || v > maxy) continue;
+        const int nLastOctave = kl[i].octave;
+        const float radius = th * scale_factors[nLastOctave];
+        int ncand;
+        if (bForward) ncand = orc_grid_query(g, u, v, radius, nLastOctave, -1, cands, nc);
+        else if (bBackward) ncand = orc_grid_query(g, u, v, radius, 0, nLastOctave, cands, nc);
+        else ncand = orc_grid_query(g, u, v, radius, nLastOctave - 1, nLastOctave + 1, cands, nc);
+        if (ncand == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < ncand; ++c) {
+            const int i2 = cands[c];
+            if (matched_last[i2] >= 0 && obs[matched_last[i2]] > 0) continue;
+            if (u_right[i2] > 0) {
+                const float ur = fp_mode == ORC_FP_GCC_FMA ? fmaf(-mbf, invzc, u) : u - mbf * invzc;
+                const float er = fabsf(ur - u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = orc_descriptor_distance(mpdesc + (size_t)i * 32, dc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            matched_last[bestIdx2] = i;
+            nmatches++;
+            if (check_ori) {
+                float rot = kl[i].angle - kc[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                hist[bin * nl + hn[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_ori) {
+        int ind1, ind2, ind3;
+        orc_three_maxima(hn, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < hn[i]; j++) { matched_last[hist[i * nl + j]] = -1; nmatches--; }
+    }
+    orc_grid_free(g);
+    free(hist); free(cands);
+    return nmatches;
+}

@@ -26,6 +26,18 @@ class Params(C.Structure):
                 ("max_cand_per_cell", C.c_int32)]
 
 
+class FrameView(C.Structure):
+    _fields_ = [("keys_un", C.c_void_p), ("desc", C.c_void_p), ("u_right", C.c_void_p), ("n", C.c_int32),
+                ("Tcw", C.c_float * 16), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("mb", C.c_float), ("mbf", C.c_float)]
+
+
+class LastFrameView(C.Structure):
+    _fields_ = [("keys_un", C.c_void_p), ("n", C.c_int32), ("has_map_point", C.c_void_p), ("world_pos", C.c_void_p),
+                ("mp_desc", C.c_void_p), ("observations", C.c_void_p), ("Tcw", C.c_float * 16)]
+
+
 class OrbxError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"orbx status {status}: {msg}")
@@ -42,7 +54,7 @@ SYMBOLS = [
     "orbx_get_stream", "orbx_set_stream", "orbx_synchronize", "orbx_profile_enable", "orbx_profile_read",
     "orbx_kernel_name", "orbx_debug_candidates", "orbx_debug_level_keypoints", "orbx_debug_blur_copy",
     "orbx_grid_create", "orbx_grid_destroy", "orbx_grid_query", "orbx_three_maxima",
-    "orbx_search_for_initialization", "orbx_stereo_match",
+    "orbx_search_for_initialization", "orbx_stereo_match", "orbx_search_by_projection_frame",
 ]
 
 _lib = None
@@ -101,6 +113,9 @@ def lib():
     L.orbx_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, i32, vp, C.POINTER(i32)]
     L.orbx_stereo_match.restype = i32
     L.orbx_stereo_match.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
+    L.orbx_search_by_projection_frame.restype = i32
+    L.orbx_search_by_projection_frame.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LastFrameView), f32, i32, i32, vp,
+                                                  C.POINTER(i32)]
     _lib = L
     return L
 

@@ -827,3 +827,108 @@ extern "C" orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int f
     if (nmatches_out) *nmatches_out = kept;
     return ORBX_OK;
 }
+
+// ---------------------------------------------------------------- a14: SearchByProjection(Frame&, const Frame&, th, bMono)
+// (src/ORBmatcher.cc:1702-1871; caller TrackWithMotionModel src/Tracking.cc:1430,1445).  GPU: Hamming matrix between
+// the representative descriptors of the last frame's MapPoints and the current frame's descriptors.  Host: projection
+// (fp32, same operation order as the reference incl. the contraction selected by fp_mode), grid gating, the
+// occupancy rule and the rotation histogram -- all order-dependent.
+static inline float orbx_gemm3(const float *a, const float *b, float c) {  // cv::gemm 3x3 * 3x1 float special case
+    const float t = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    return (float)((double)t * 1.0 + (double)c * 1.0);
+}
+
+extern "C" orbx_status orbx_search_by_projection_frame(orbx_handle *h, const orbx_frame_view *cur,
+                                                       const orbx_last_frame_view *last, float th, int mono,
+                                                       int check_orientation, int32_t *matched_last, int *nmatches_out) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (!cur || !last || !matched_last || !nmatches_out || cur->n < 0 || last->n < 0)
+        return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    const int nc = cur->n, nl = last->n, HISTO = 30, TH_HIGH_ = 100;
+    *nmatches_out = 0;
+    for (int i = 0; i < nc; ++i) matched_last[i] = -1;
+    if (nc == 0 || nl == 0) return ORBX_OK;
+    if (!cur->keys_un || !cur->desc || !cur->u_right || !last->keys_un || !last->has_map_point || !last->world_pos ||
+        !last->mp_desc || !last->observations)
+        return fail(ORBX_BAD_ARGUMENT, "null frame field");
+    const bool fma_mode = h->p.fp_mode == ORBX_FP_GCC_FMA;
+    // GPU distances: rows = last-frame points that own a MapPoint
+    std::vector<int> rows, rpos(nl, -1);
+    for (int i = 0; i < nl; ++i) if (last->has_map_point[i]) { rpos[i] = (int)rows.size(); rows.push_back(i); }
+    std::vector<uint16_t> D;
+    if (!rows.empty()) {
+        std::vector<uint8_t> q(rows.size() * 32);
+        for (size_t r = 0; r < rows.size(); ++r) memcpy(&q[r * 32], last->mp_desc + (size_t)rows[r] * 32, 32);
+        D.resize(rows.size() * (size_t)nc);
+        orbx_status st = orbx_hamming_matrix(h, q.data(), (int)rows.size(), cur->desc, nc, D.data());
+        if (st != ORBX_OK) return st;
+    }
+    float Rcw[9], tcw[3], Rlw[9], tlw[3], twc[3], tlc[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) { Rcw[3 * r + c] = cur->Tcw[4 * r + c]; Rlw[3 * r + c] = last->Tcw[4 * r + c]; }
+        tcw[r] = cur->Tcw[4 * r + 3]; tlw[r] = last->Tcw[4 * r + 3];
+    }
+    for (int r = 0; r < 3; ++r) {
+        const float t = Rcw[0 + r] * tcw[0] + Rcw[3 + r] * tcw[1] + Rcw[6 + r] * tcw[2];
+        twc[r] = (float)((double)t * -1.0);
+    }
+    for (int r = 0; r < 3; ++r) tlc[r] = orbx_gemm3(&Rlw[3 * r], twc, tlw[r]);
+    const bool bForward = tlc[2] > cur->mb && !mono, bBackward = -tlc[2] > cur->mb && !mono;
+    orbx_grid *grid = orbx_grid_create(cur->keys_un, nc, cur->min_x, cur->max_x, cur->min_y, cur->max_y);
+    if (!grid) return fail(ORBX_BAD_ARGUMENT, "bad image bounds");
+    std::vector<std::vector<int>> rotHist(HISTO);
+    const float factor = HISTO / 360.0f;  // fork value (src/ORBmatcher.cc:1713)
+    std::vector<int> cands(nc);
+    int nmatches = 0;
+    for (int i = 0; i < nl; ++i) {
+        if (!last->has_map_point[i]) continue;
+        float pc[3];
+        for (int r = 0; r < 3; ++r) pc[r] = orbx_gemm3(&Rcw[3 * r], last->world_pos + 3 * (size_t)i, tcw[r]);
+        const float invzc = (float)(1.0 / pc[2]);
+        if (invzc < 0) continue;
+        float u, v;
+        if (fma_mode) { u = std::fmaf(cur->fx * pc[0], invzc, cur->cx); v = std::fmaf(cur->fy * pc[1], invzc, cur->cy); }
+        else { u = cur->fx * pc[0] * invzc + cur->cx; v = cur->fy * pc[1] * invzc + cur->cy; }
+        if (u < cur->min_x || u > cur->max_x || v < cur->min_y || v > cur->max_y) continue;
+        const int oct = last->keys_un[i].octave;
+        if (oct < 0 || oct >= h->p.nlevels) continue;
+        const float radius = th * h->tab.scale[oct];
+        const int ncand = bForward ? orbx_grid_query(grid, u, v, radius, oct, -1, cands.data(), nc)
+                          : bBackward ? orbx_grid_query(grid, u, v, radius, 0, oct, cands.data(), nc)
+                                      : orbx_grid_query(grid, u, v, radius, oct - 1, oct + 1, cands.data(), nc);
+        if (ncand == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < ncand; ++c) {
+            const int i2 = cands[c];
+            if (matched_last[i2] >= 0 && last->observations[matched_last[i2]] > 0) continue;
+            if (cur->u_right[i2] > 0) {
+                const float ur = fma_mode ? std::fmaf(-cur->mbf, invzc, u) : u - cur->mbf * invzc;
+                if (fabsf(ur - cur->u_right[i2]) > radius) continue;
+            }
+            const int dist = (int)D[(size_t)rpos[i] * nc + i2];
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH_) {
+            matched_last[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                float rot = last->keys_un[i].angle - cur->keys_un[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO) bin = 0;
+                if (bin >= 0 && bin < HISTO) rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {
+        int32_t sizes[30]; int i1, i2, i3;
+        for (int i = 0; i < HISTO; ++i) sizes[i] = (int)rotHist[i].size();
+        orbx_three_maxima(sizes, HISTO, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO; ++i)
+            if (i != i1 && i != i2 && i != i3)
+                for (int idx2 : rotHist[i]) { matched_last[idx2] = -1; nmatches--; }
+    }
+    orbx_grid_destroy(grid);
+    *nmatches_out = nmatches;
+    return ORBX_OK;
+}

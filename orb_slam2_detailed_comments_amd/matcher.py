@@ -63,6 +63,29 @@ class ORBmatcher:
             vbPrevMatched[...] = pm
         return n.value, m12[:F1.N].copy()
 
+    # ---- SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1702-1871)
+    def SearchByProjection(self, cur, last, th, bMono, *, Tcw, Tlw, K, mb, mbf, has_map_point, world_pos, mp_desc,
+                           observations):
+        """cur, last: frame.Frame; MapPoint state of the last frame as arrays.  Returns (nmatches, matched_last[cur.N])."""
+        import ctypes as C
+        keep = [np.ascontiguousarray(a, t) for a, t in ((cur.mvuRight, np.float32), (has_map_point, np.uint8),
+                                                         (world_pos, np.float32), (mp_desc, np.uint8),
+                                                         (observations, np.int32))]
+        cv, lv = _capi.FrameView(), _capi.LastFrameView()
+        cv.keys_un, cv.desc, cv.u_right, cv.n = cur.mvKeysUn.ctypes.data, cur.mDescriptors.ctypes.data, keep[0].ctypes.data, cur.N
+        cv.Tcw[:] = [float(v) for v in np.asarray(Tcw, np.float32).reshape(16)]
+        cv.fx, cv.fy, cv.cx, cv.cy = [float(v) for v in K]
+        cv.min_x, cv.max_x, cv.min_y, cv.max_y = cur.bounds
+        cv.mb, cv.mbf = float(mb), float(mbf)
+        lv.keys_un, lv.n = last.mvKeysUn.ctypes.data, last.N
+        lv.has_map_point, lv.world_pos, lv.mp_desc, lv.observations = (k.ctypes.data for k in keep[1:])
+        lv.Tcw[:] = [float(v) for v in np.asarray(Tlw, np.float32).reshape(16)]
+        out = np.full(max(cur.N, 1), -1, np.int32)
+        n = C.c_int(0)
+        check(self._L.orbx_search_by_projection_frame(self._ex.handle, C.byref(cv), C.byref(lv), float(th), int(bMono),
+                                                      int(self.mbCheckOrientation), ptr(out), C.byref(n)))
+        return n.value, out[:cur.N].copy()
+
     # ---- ComputeThreeMaxima (src/ORBmatcher.cc:2026-2068): 30 numbers, host side
     @staticmethod
     def ComputeThreeMaxima(sizes):

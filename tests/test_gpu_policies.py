@@ -71,3 +71,39 @@ def test_stereo_identical_images_and_no_right_keypoints():
     assert np.array_equal(FL.mvDepth.view(np.uint32), od.view(np.uint32))
     F0 = Frame(kR[:0], dR[:0], 640, 480)
     assert FL.ComputeStereoMatches(F0, exL, exR, 0.1, 40.0) == 0 and (FL.mvuRight == -1).all()
+
+
+@pytest.mark.parametrize("mono,th,motion", [(True, 15.0, "side"), (False, 7.0, "side"), (False, 15.0, "forward"),
+                                            (False, 15.0, "backward")])
+def test_search_by_projection_frame_to_frame(mono, th, motion):
+    """TrackWithMotionModel's matcher (src/Tracking.cc:1430,1445): last frame's MapPoints at constant depth, the
+    current camera moved so that projections follow the translated synthetic scene."""
+    frames = synth.stream(640, 480, 2, stream_id=4)
+    ex = ORBextractor(1000, max_batch=2)
+    (k0, d0), (k1, d1) = ex.extract_batch(frames)
+    last, cur = Frame(k0, d0, 640, 480), Frame(k1, d1, 640, 480)
+    fx = fy = 500.0; cx, cy = 339.0, 259.0                      # principal point in padded coordinates
+    Z = 2.0
+    rng = np.random.default_rng(0)
+    n0 = len(k0)
+    has_mp = (rng.uniform(size=n0) < 0.8).astype(np.uint8)
+    obs = rng.integers(0, 3, n0).astype(np.int32)              # some temporal points with 0 observations
+    xw = np.stack([(k0["x"] - cx) / fx * Z, (k0["y"] - cy) / fy * Z, np.full(n0, Z)], 1).astype(np.float32)
+    Tlw = np.eye(4, dtype=np.float32)
+    Tcw = np.eye(4, dtype=np.float32)
+    Tcw[0, 3], Tcw[1, 3] = -3.0 / fx * Z, -2.0 / fy * Z        # scene shifted by (+3, +2) px between t=0 and t=1
+    mb, mbf = 0.1, 40.0
+    if motion == "forward":
+        Tcw[2, 3] = -0.3
+    if motion == "backward":
+        Tcw[2, 3] = 0.3
+    if not mono:                                               # give some current features a right coordinate
+        cur.mvuRight[::3] = (k1["x"][::3] - mbf / Z).astype(np.float32)
+    m = ORBmatcher(0.9, True, extractor=ex)
+    n, matched = m.SearchByProjection(cur, last, th, mono, Tcw=Tcw, Tlw=Tlw, K=(fx, fy, cx, cy), mb=mb, mbf=mbf,
+                                      has_map_point=has_mp, world_pos=xw, mp_desc=d0, observations=obs)
+    on, omatched = oracle.search_by_projection_ff(k1, d1, cur.mvuRight, Tcw, (fx, fy, cx, cy), (0, 640, 0, 480), mb, mbf,
+                                                  ex.GetScaleFactors(), k0, has_mp, xw, d0, obs, Tlw, th, mono)
+    assert n == on and np.array_equal(matched, omatched)
+    if motion == "side":
+        assert n > 100
