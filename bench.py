@@ -45,8 +45,8 @@ def algorithmic_bytes(ex, w, h, n_kp):
         "k_fast_cells": Pt,
         "k_quadtree": 0,
         "k_orient": n_kp * 749,
-        "k_blur": 2 * Pt,
-        "k_describe": n_kp * 512 + n_kp * 60,
+        "k_blur": 0,                                   # fused into k_describe (the blurred image is never written)
+        "k_describe": 2 * Pt + n_kp * 512 + n_kp * 60,  # blur read+write + descriptor taps + output
         "k_match": 2 * n_kp * 32 + n_kp * 12,
     }
 

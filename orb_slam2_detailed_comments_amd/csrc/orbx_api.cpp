@@ -53,6 +53,7 @@ struct orbx_handle {
     int out_cap = 0;
     int last_batch = 0;
     int mk_w = 0, mk_h = 0, mk_total = 0;   // orbx_max_keypoints cache
+    bool blur_valid = false;                // d_blur holds the blurred pyramid of the last batch
     // profiling
     uint32_t prof_mask = 0;
     std::vector<ProfPair> pending;
@@ -308,10 +309,9 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
                            h->ncap, h->lds_keys); }
     { ProfScope ps(h, ORBX_K_ORIENT);
       orbx_launch_orient(s, g, B, h->d_pyr, h->d_lvl_kp, h->d_lvl_count, h->d_lvl_angle); }
-    { ProfScope ps(h, ORBX_K_BLUR);
-      orbx_launch_blur(s, g, B, h->d_pyr, h->d_blur); }
+    h->blur_valid = false;  // the Gaussian is fused into k_describe; the full blurred image is only built on request
     { ProfScope ps(h, ORBX_K_DESC);
-      orbx_launch_describe(s, g, B, h->d_blur, h->d_lvl_kp, h->d_lvl_count, h->d_lvl_angle, d_kps, d_desc, d_counts,
+      orbx_launch_describe(s, g, B, h->d_pyr, h->d_lvl_kp, h->d_lvl_count, h->d_lvl_angle, d_kps, d_desc, d_counts,
                            d_status, cap); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ORBX_HIP_ERROR, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -441,7 +441,15 @@ extern "C" orbx_status orbx_pyramid_level_copy(orbx_handle *h, int frame, int le
     return copy_level(h, h ? h->d_pyr : nullptr, frame, level, dst, dst_stride);
 }
 extern "C" orbx_status orbx_debug_blur_copy(orbx_handle *h, int frame, int level, uint8_t *dst, int dst_stride) {
-    return copy_level(h, h ? h->d_blur : nullptr, frame, level, dst, dst_stride);
+    orbx_status st = check_level(h, frame, level);
+    if (st != ORBX_OK) return st;
+    if (!h->blur_valid) {  // stand-alone k_blur over the resident pyramid (same arithmetic as the fused path)
+        HIPCHK(hipSetDevice(h->dev));
+        { ProfScope ps(h, ORBX_K_BLUR);
+          orbx_launch_blur(h->stream, h->dg, h->last_batch, h->d_pyr, h->d_blur); }
+        h->blur_valid = true;
+    }
+    return copy_level(h, h->d_blur, frame, level, dst, dst_stride);
 }
 
 // ---------------------------------------------------------------- per-stage inspection

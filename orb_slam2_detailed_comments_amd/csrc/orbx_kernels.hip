@@ -106,188 +106,207 @@ __device__ __forceinline__ bool orbx_arc9(uint32_t mask16) {
     return (a & 0xffffu) != 0;
 }
 
-// dynamic LDS: tile[rows*TP] | score[rows*TP] | listA u16[lcap] | listB u16[lcap] | corn u16[lcap] | surv u32[scap]
-// TP = tile pitch in bytes (multiple of 4)
-__device__ __forceinline__ int orbx_wave_compact(bool flag, uint16_t *list, int n, uint16_t value) {
-    const unsigned long long bal = __ballot(flag);
-    if (flag) {
-        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-        list[n + rank] = value;
-    }
-    return n + __popcll(bal);
+// dynamic LDS: tile[rows*TP] | score[rows*TP] | list u16[lcap] (two-ended) | corn u16[lcap]; TP = tile pitch (%4 == 0)
+__device__ __forceinline__ int orbx_wave_rank(unsigned long long bal) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+}
+// LDS traffic inside one wave is ordered by the hardware; this only stops the compiler from reordering across phases
+__device__ __forceinline__ void orbx_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// a 9-arc of the 16-ring contains at least one pixel of every opposite pair (k, k+8): necessary condition
-__device__ __forceinline__ bool orbx_compass(int v, int r0, int r4, int r8, int r12, int th) {
-    const int hi = v + th, lo = v - th;
-    const int br = ((int)(r0 > hi) | (int)(r8 > hi)) & ((int)(r4 > hi) | (int)(r12 > hi));
-    const int dk = ((int)(r0 < lo) | (int)(r8 < lo)) & ((int)(r4 < lo) | (int)(r12 < lo));
-    return (br | dk) != 0;
-}
+#define FAST_CPW 4      // cells per wave: prologue amortised, next tile prefetched into registers during compute
+#define FAST_PF 10      // prefetch registers: 4 rows x 16 dwords per step -> cells up to 40 rows x 61 px (all but tiny levels)
 
-__global__ __launch_bounds__(64) void k_fast_cells(DGeom g, const OrbxCell *__restrict__ cells,
+__global__ __launch_bounds__(64, 5) void k_fast_cells(DGeom g, const OrbxCell *__restrict__ cells,
                                                    const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
                                                    int *__restrict__ cell_count, int FAST_TP, int rows, int lcap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
     const int lcap_b = (2 * lcap + 3) & ~3;
     uint32_t *s_tile = (uint32_t *)fast_smem;
     uint8_t *s_score = fast_smem + rows * FAST_TP;
-    uint16_t *s_listA = (uint16_t *)(fast_smem + 2 * rows * FAST_TP);
-    uint16_t *s_listB = (uint16_t *)(fast_smem + 2 * rows * FAST_TP + lcap_b);
-    uint16_t *s_corn = (uint16_t *)(fast_smem + 2 * rows * FAST_TP + 2 * lcap_b);
-    uint32_t *s_surv = (uint32_t *)(fast_smem + 2 * rows * FAST_TP + 3 * lcap_b);
+    uint16_t *s_list = (uint16_t *)(fast_smem + 2 * rows * FAST_TP);          // [0,nA): compass@ini; (lcap-nB, lcap]: compass@min only
+    uint16_t *s_corn = (uint16_t *)(fast_smem + 2 * rows * FAST_TP + lcap_b);
     const int lane = threadIdx.x;
-    const OrbxCell c = cells[blockIdx.x];
     const int f = blockIdx.y;
-    const DLevel &L = g.lv[c.level];
-    const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;
-    const int cw = c.cw, ch = c.ch;
-    // ---- stage the tile with aligned dword loads (16 dword columns x 4 rows per wave step)
-    const int xa = c.x0 & ~3, shift = c.x0 & 3;
-    const int ndw = (shift + cw + 3) >> 2;
-    // all global loads are issued before the first LDS store (one exposed memory latency per cell, not one per row)
-    {
-        const int rq = lane >> 4, dq = lane & 15;
-        uint32_t tv[17];
-        const int dqc = min(dq, ndw - 1);
-        const uint8_t *srcc = img + (long long)c.y0 * L.pitch + xa + 4 * dqc;
-#pragma unroll
-        for (int k = 0; k < 17; ++k)
-            if (4 * k < ch)  // wave-uniform; rows past the cell are clamped (re-read), never out of bounds
-                tv[k] = *(const uint32_t *)(srcc + (long long)min(4 * k + rq, ch - 1) * L.pitch);
-#pragma unroll
-        for (int k = 0; k < 17; ++k)
-            if (4 * k < ch) {
-                const int r = 4 * k + rq;
-                if (r < ch && dq < ndw) s_tile[r * (FAST_TP / 4) + dq] = tv[k];
-            }
-        if (ndw > 16)  // cells wider than 61 px (tiny pyramid levels only)
-            for (int r = rq; r < ch; r += 4)
-                for (int d = 16 + dq; d < ndw; d += 16)
-                    s_tile[r * (FAST_TP / 4) + d] = *(const uint32_t *)(img + (long long)(c.y0 + r) * L.pitch + xa + 4 * d);
-    }
-    for (int i = lane; i < ch * (FAST_TP / 4); i += 64) ((uint32_t *)s_score)[i] = 0;
-    const uint8_t *tile = (const uint8_t *)s_tile + shift;
+    const int half = lane >> 5, lcol = lane & 31;
+    const int rq = lane >> 4, dq = lane & 15;
+    const bool two_th = g.min_th != g.ini_th;
     // ring offsets in the LDS tile
     const int ro[16] = {3 * FAST_TP,      3 * FAST_TP + 1,  2 * FAST_TP + 2,  FAST_TP + 3, 3,  -FAST_TP + 3,
                         -2 * FAST_TP + 2, -3 * FAST_TP + 1, -3 * FAST_TP,     -3 * FAST_TP - 1, -2 * FAST_TP - 2,
                         -FAST_TP - 3,     -3,               FAST_TP - 3,      2 * FAST_TP - 2,  3 * FAST_TP - 1};
-    const int half = lane >> 5, lcol = lane & 31;
-    const bool two_th = g.min_th != g.ini_th;
-    __syncthreads();
-    // ---- phase 1a: compass pre-test of EVERY interior pixel at both thresholds in one sweep (two rows per lane
-    // per step for load-level parallelism); survivors are compacted so that the full ring test runs on dense lanes
-    int nA = 0, nB = 0;
-    for (int yb = 3; yb < ch - 3; yb += 4) {
-        for (int x0 = 3; x0 < cw - 3; x0 += 32) {
-            const int lx = x0 + lcol;
-            const int ly0 = yb + 2 * half, ly1 = ly0 + 1;
-            const bool act0 = lx < cw - 3 && ly0 < ch - 3, act1 = lx < cw - 3 && ly1 < ch - 3;
-            const uint8_t *p0 = tile + (act0 ? ly0 : 3) * FAST_TP + (act0 ? lx : 3);
-            const uint8_t *p1 = tile + (act1 ? ly1 : 3) * FAST_TP + (act1 ? lx : 3);
-            const int v0 = p0[0], a0 = p0[ro[0]], a4 = p0[ro[4]], a8 = p0[ro[8]], a12 = p0[ro[12]];
-            const int v1 = p1[0], b0 = p1[ro[0]], b4 = p1[ro[4]], b8 = p1[ro[8]], b12 = p1[ro[12]];
-            const bool A0 = (int)act0 & (int)orbx_compass(v0, a0, a4, a8, a12, g.ini_th);
-            const bool A1 = (int)act1 & (int)orbx_compass(v1, b0, b4, b8, b12, g.ini_th);
-            nA = orbx_wave_compact(A0, s_listA, nA, (uint16_t)((ly0 << 8) | lx));
-            nA = orbx_wave_compact(A1, s_listA, nA, (uint16_t)((ly1 << 8) | lx));
-            if (two_th) {
-                const bool B0 = (int)act0 & (int)orbx_compass(v0, a0, a4, a8, a12, g.min_th);
-                const bool B1 = (int)act1 & (int)orbx_compass(v1, b0, b4, b8, b12, g.min_th);
-                nB = orbx_wave_compact(B0, s_listB, nB, (uint16_t)((ly0 << 8) | lx));
-                nB = orbx_wave_compact(B1, s_listB, nB, (uint16_t)((ly1 << 8) | lx));
-            }
-        }
+    const int cell0 = blockIdx.x * FAST_CPW;
+    const int ncell = min(FAST_CPW, g.ncells - cell0);
+    uint32_t tv[FAST_PF];
+    // ---- prefetch of the first tile (all loads in flight before anything waits on them)
+    OrbxCell c = cells[cell0];
+    {
+        const DLevel &L = g.lv[c.level];
+        const int ndw = ((c.x0 & 3) + c.cw + 3) >> 2;
+        const uint8_t *src = pyr + (long long)f * g.pyr_bytes + L.off + (long long)c.y0 * L.pitch + (c.x0 & ~3) + 4 * min(dq, ndw - 1);
+#pragma unroll
+        for (int k = 0; k < FAST_PF; ++k) tv[k] = *(const uint32_t *)(src + (long long)min(4 * k + rq, c.ch - 1) * L.pitch);
     }
-    __syncthreads();
-    int nsurv = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        const int th = pass == 0 ? g.ini_th : g.min_th;
-        const uint16_t *list = pass == 0 ? s_listA : s_listB;
-        const int nlist = pass == 0 ? nA : nB;
-        // ---- phase 1b: full 16-ring test of the pre-selected pixels
-        int ncorn = 0;
-        for (int e0 = 0; e0 < nlist; e0 += 64) {
-            const int e = e0 + lane;
-            const bool valid = e < nlist;
-            const uint16_t code = valid ? list[e] : (uint16_t)((3 << 8) | 3);
-            const uint8_t *ptr = tile + (code >> 8) * FAST_TP + (code & 0xff);
-            const int v = ptr[0];
-            const int hi = v + th, lo = v - th;
-            uint32_t bright = 0, dark = 0;
+    for (int ci = 0; ci < ncell; ++ci) {
+        const DLevel &L = g.lv[c.level];
+        const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;
+        const int cw = c.cw, ch = c.ch;
+        const int xa = c.x0 & ~3, shift = c.x0 & 3;
+        const int ndw = (shift + cw + 3) >> 2;
+        // ---- tile: prefetched registers -> LDS; rows / columns beyond the register window come straight from memory
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int x = ptr[ro[k]];
-                bright |= (uint32_t)(x > hi) << k;
-                dark |= (uint32_t)(x < lo) << k;
-            }
-            const bool corner = (int)valid & ((int)orbx_arc9(bright) | (int)orbx_arc9(dark));
-            ncorn = orbx_wave_compact(corner, s_corn, ncorn, code);
+        for (int k = 0; k < FAST_PF; ++k) {
+            const int r = 4 * k + rq;
+            if (r < ch && dq < ndw) s_tile[r * (FAST_TP / 4) + dq] = tv[k];
         }
-        __syncthreads();
-        // ---- phase 2: score of every corner: max(th, max_arc min d, max_arc min -d) - 1
-        for (int e = lane; e < ncorn; e += 64) {
-            const int lx = s_corn[e] & 0xff, ly = s_corn[e] >> 8;
-            const uint8_t *ptr = tile + ly * FAST_TP + lx;
-            const int v = ptr[0];
-            int d[16];
+        if (ch > 4 * FAST_PF || ndw > 16)
+            for (int r = rq; r < ch; r += 4)
+                for (int d = dq; d < ndw; d += 16)
+                    if (r >= 4 * FAST_PF || d >= 16)
+                        s_tile[r * (FAST_TP / 4) + d] = *(const uint32_t *)(img + (long long)(c.y0 + r) * L.pitch + xa + 4 * d);
+        for (int i = lane; i < ch * (FAST_TP / 4); i += 64) ((uint32_t *)s_score)[i] = 0;
+        // ---- prefetch the next cell's tile; it lands while this cell is being processed
+        const OrbxCell cur = c;
+        if (ci + 1 < ncell) {
+            c = cells[cell0 + ci + 1];
+            const DLevel &Ln = g.lv[c.level];
+            const int ndwn = ((c.x0 & 3) + c.cw + 3) >> 2;
+            const uint8_t *src = pyr + (long long)f * g.pyr_bytes + Ln.off + (long long)c.y0 * Ln.pitch + (c.x0 & ~3) + 4 * min(dq, ndwn - 1);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) d[k] = v - (int)ptr[ro[k]];
-            int mn2[16], mx2[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-            int mn4[16], mx4[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-            int a0 = th, b0 = -th;  // a0: best "ring darker" arc, b0: -(best "ring brighter" arc)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-                const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-                a0 = max(a0, mn9);
-                b0 = min(b0, mx9);
-            }
-            s_score[ly * FAST_TP + lx] = (uint8_t)(max(a0, -b0) - 1);
+            for (int k = 0; k < FAST_PF; ++k) tv[k] = *(const uint32_t *)(src + (long long)min(4 * k + rq, c.ch - 1) * Ln.pitch);
         }
-        __syncthreads();
-        // ---- phase 3: 3x3 strict NMS among the corners of THIS cell only
-        nsurv = 0;
-        for (int e0 = 0; e0 < ncorn; e0 += 64) {
-            const int e = e0 + lane;
-            const bool valid = e < ncorn;
-            const uint16_t code = valid ? s_corn[e] : (uint16_t)((3 << 8) | 3);
-            const int lx = code & 0xff, ly = code >> 8;
-            const uint8_t *sp = s_score + ly * FAST_TP + lx;
-            const int sc = sp[0];
-            const int n0 = sp[1], n1 = sp[-1], n2 = sp[-FAST_TP - 1], n3 = sp[-FAST_TP], n4 = sp[-FAST_TP + 1],
-                      n5 = sp[FAST_TP - 1], n6 = sp[FAST_TP], n7 = sp[FAST_TP + 1];
-            const bool keep = (int)valid & (int)(sc > n0) & (int)(sc > n1) & (int)(sc > n2) & (int)(sc > n3) &
-                              (int)(sc > n4) & (int)(sc > n5) & (int)(sc > n6) & (int)(sc > n7);
-            const uint32_t rec = (uint32_t)lx | ((uint32_t)ly << 8) | ((uint32_t)sc << 16);
-            const unsigned long long bal = __ballot(keep);
-            if (keep) {
-                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-                s_surv[nsurv + rank] = rec;
+        const uint8_t *tile = (const uint8_t *)s_tile + shift;
+        orbx_wave_sync();
+        // ---- phase 1a: compass pre-test of EVERY interior pixel for both thresholds in one sweep.  A 9-arc of the
+        // 16-ring contains one pixel of every opposite pair, so e = max(min(max(r0,r8),max(r4,r12)) - v,
+        // v - max(min(r0,r8),min(r4,r12))) > th is necessary for a corner.  Two rows per lane per step.
+        int nA = 0, nB = 0;
+        for (int yb = 3; yb < ch - 3; yb += 4) {
+            for (int x0 = 3; x0 < cw - 3; x0 += 32) {
+                const int lx = x0 + lcol;
+                const int ly0 = yb + 2 * half, ly1 = ly0 + 1;
+                const bool act0 = lx < cw - 3 && ly0 < ch - 3, act1 = lx < cw - 3 && ly1 < ch - 3;
+                const uint8_t *p0 = tile + (act0 ? ly0 : 3) * FAST_TP + (act0 ? lx : 3);
+                const uint8_t *p1 = tile + (act1 ? ly1 : 3) * FAST_TP + (act1 ? lx : 3);
+                const int v0 = p0[0], a0 = p0[ro[0]], a4 = p0[ro[4]], a8 = p0[ro[8]], a12 = p0[ro[12]];
+                const int v1 = p1[0], b0 = p1[ro[0]], b4 = p1[ro[4]], b8 = p1[ro[8]], b12 = p1[ro[12]];
+                int e0 = max(min(max(a0, a8), max(a4, a12)) - v0, v0 - max(min(a0, a8), min(a4, a12)));
+                int e1 = max(min(max(b0, b8), max(b4, b12)) - v1, v1 - max(min(b0, b8), min(b4, b12)));
+                e0 = act0 ? e0 : -1;
+                e1 = act1 ? e1 : -1;
+                const uint16_t code0 = (uint16_t)((ly0 << 8) | lx), code1 = (uint16_t)((ly1 << 8) | lx);
+                {   // front of the list: passes at iniThFAST
+                    const unsigned long long m0 = __ballot(e0 > g.ini_th), m1 = __ballot(e1 > g.ini_th);
+                    if (e0 > g.ini_th) s_list[nA + orbx_wave_rank(m0)] = code0;
+                    nA += __popcll(m0);
+                    if (e1 > g.ini_th) s_list[nA + orbx_wave_rank(m1)] = code1;
+                    nA += __popcll(m1);
+                }
+                if (two_th) {   // back of the list: passes at minThFAST only
+                    const bool q0 = e0 > g.min_th && e0 <= g.ini_th, q1 = e1 > g.min_th && e1 <= g.ini_th;
+                    const unsigned long long m0 = __ballot(q0), m1 = __ballot(q1);
+                    if (q0) s_list[lcap - 1 - (nB + orbx_wave_rank(m0))] = code0;
+                    nB += __popcll(m0);
+                    if (q1) s_list[lcap - 1 - (nB + orbx_wave_rank(m1))] = code1;
+                    nB += __popcll(m1);
+                }
             }
-            nsurv += __popcll(bal);
         }
-        __syncthreads();
-        if (nsurv > 0 || !two_th) break;  // vKeysCell.empty() -> retry with minThFAST (:1519-1527)
-        // the retry recomputes every score with the lower threshold: clear the scores of the first attempt
-        for (int e = lane; e < ncorn; e += 64) s_score[(s_corn[e] >> 8) * FAST_TP + (s_corn[e] & 0xff)] = 0;
-        __syncthreads();
-    }
-    // ---- emit into this cell's private slot range: no atomics, no dependence on other cells
-    if (lane == 0) cell_count[(long long)f * g.ncells + blockIdx.x] = nsurv;
-    uint2 *out = cand + (long long)f * g.cand_total + L.cand_begin + c.slot_begin;
-    const int nw = min(nsurv, c.slot_cap);
-    for (int e = lane; e < nw; e += 64) {
-        const uint32_t rec = s_surv[e];
-        const int lx = rec & 0xff, ly = (rec >> 8) & 0xff, sc = rec >> 16;
-        uint2 o;
-        o.x = (uint32_t)(lx + c.offx) | ((uint32_t)(ly + c.offy) << 12) | ((uint32_t)sc << 24);
-        o.y = ((uint32_t)c.idx_in_level << 12) | ((uint32_t)ly << 6) | (uint32_t)lx;  // emission order key
-        out[e] = o;
+        orbx_wave_sync();
+        uint2 *out = cand + (long long)f * g.cand_total + L.cand_begin + cur.slot_begin;
+        int nsurv = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int th = pass == 0 ? g.ini_th : g.min_th;
+            const int nlist = pass == 0 ? nA : nA + nB;
+            // ---- phase 1b: full 16-ring test of the pre-selected pixels
+            int ncorn = 0;
+            for (int e0 = 0; e0 < nlist; e0 += 64) {
+                const int e = e0 + lane;
+                const bool valid = e < nlist;
+                const uint16_t code = !valid ? (uint16_t)((3 << 8) | 3) : e < nA ? s_list[e] : s_list[lcap - 1 - (e - nA)];
+                const uint8_t *ptr = tile + (code >> 8) * FAST_TP + (code & 0xff);
+                const int v = ptr[0];
+                const int hi = v + th, lo = v - th;
+                uint32_t bright = 0, dark = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int x = ptr[ro[k]];
+                    bright |= (uint32_t)(x > hi) << k;
+                    dark |= (uint32_t)(x < lo) << k;
+                }
+                const bool corner = (int)valid & ((int)orbx_arc9(bright) | (int)orbx_arc9(dark));
+                const unsigned long long m = __ballot(corner);
+                if (corner) s_corn[ncorn + orbx_wave_rank(m)] = code;
+                ncorn += __popcll(m);
+            }
+            orbx_wave_sync();
+            // ---- phase 2: score of every corner: max(th, max_arc min d, max_arc min -d) - 1
+            for (int e = lane; e < ncorn; e += 64) {
+                const int lx = s_corn[e] & 0xff, ly = s_corn[e] >> 8;
+                const uint8_t *ptr = tile + ly * FAST_TP + lx;
+                const int v = ptr[0];
+                int d[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) d[k] = v - (int)ptr[ro[k]];
+                // sliding 9-window extrema over the circular ring by doubling (2, 4, 8, +1); the two polarities are
+                // evaluated one after the other to keep the live register set small
+                int a0 = th, b0 = -th;  // a0: best "ring darker" arc, b0: -(best "ring brighter" arc)
+                {
+                    int m2[16], m4[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) m2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) a0 = max(a0, min(min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
+                }
+                {
+                    int m2[16], m4[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) m2[k] = max(d[k], d[(k + 1) & 15]);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) m4[k] = max(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) b0 = min(b0, max(max(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
+                }
+                s_score[ly * FAST_TP + lx] = (uint8_t)(max(a0, -b0) - 1);
+            }
+            orbx_wave_sync();
+            // ---- phase 3: 3x3 strict NMS among the corners of THIS cell only; survivors go straight to the cell's
+            // private slot range (no atomics, no staging)
+            nsurv = 0;
+            for (int e0 = 0; e0 < ncorn; e0 += 64) {
+                const int e = e0 + lane;
+                const bool valid = e < ncorn;
+                const uint16_t code = valid ? s_corn[e] : (uint16_t)((3 << 8) | 3);
+                const int lx = code & 0xff, ly = code >> 8;
+                const uint8_t *sp = s_score + ly * FAST_TP + lx;
+                const int sc = sp[0];
+                const int n0 = sp[1], n1 = sp[-1], n2 = sp[-FAST_TP - 1], n3 = sp[-FAST_TP], n4 = sp[-FAST_TP + 1],
+                          n5 = sp[FAST_TP - 1], n6 = sp[FAST_TP], n7 = sp[FAST_TP + 1];
+                const bool keep = (int)valid & (int)(sc > n0) & (int)(sc > n1) & (int)(sc > n2) & (int)(sc > n3) &
+                                  (int)(sc > n4) & (int)(sc > n5) & (int)(sc > n6) & (int)(sc > n7);
+                const unsigned long long m = __ballot(keep);
+                const int slot = nsurv + orbx_wave_rank(m);
+                if (keep && slot < cur.slot_cap) {
+                    uint2 o;
+                    o.x = (uint32_t)(lx + cur.offx) | ((uint32_t)(ly + cur.offy) << 12) | ((uint32_t)sc << 24);
+                    o.y = ((uint32_t)cur.idx_in_level << 12) | ((uint32_t)ly << 6) | (uint32_t)lx;  // emission order key
+                    out[slot] = o;
+                }
+                nsurv += __popcll(m);
+            }
+            if (nsurv > 0 || !two_th) break;  // vKeysCell.empty() -> retry with minThFAST (:1519-1527)
+            // the retry recomputes every score with the lower threshold: clear the scores of the first attempt
+            orbx_wave_sync();
+            for (int e = lane; e < ncorn; e += 64) s_score[(s_corn[e] >> 8) * FAST_TP + (s_corn[e] & 0xff)] = 0;
+            orbx_wave_sync();
+        }
+        if (lane == 0) cell_count[(long long)f * g.ncells + cell0 + ci] = nsurv;
+        orbx_wave_sync();   // the next cell overwrites tile / score / lists
     }
 }
 
@@ -749,14 +768,25 @@ __global__ __launch_bounds__(256) void k_blur(DGeom g, const uint8_t *__restrict
 // pattern rearranged per lane: entry l holds, for round r = 0..3, the pair r*64 + l as (x1, y1, x2, y2) int8
 __constant__ int4 c_pattern_lane[64];
 
-__global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__restrict__ blur,
+// The 7x7 Gaussian (reference :2039-2047) is fused in: only a 43x43 neighbourhood of each keypoint is ever sampled
+// (|tap| <= 18, +3 px filter support), so each wave stages that patch of the UN-blurred level in LDS, runs the
+// fixed-point row pass over it (4 pixels per item, as k_blur does) and evaluates the column pass only at the 512 tap
+// positions.  The blurred image is never written: 2P bytes of HBM traffic per frame disappear.  Arithmetic is the
+// same as k_blur's (8-bit kernel, float column path for x < (w & ~3), integer tail), so descriptors are unchanged.
+#define DS_R 21                 // patch radius: 18 (taps) + 3 (filter support)
+#define DS_W (2 * DS_R + 1)     // 43
+#define DS_PP 48                // LDS patch pitch in bytes (43 + up to 3 alignment shift, multiple of 4)
+#define DS_HC 40                // row-pass outputs per row (37 needed, computed in groups of 4)
+__global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
                                                   const uint32_t *__restrict__ lvl_kp,
                                                   const int *__restrict__ lvl_count,
                                                   const float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int *__restrict__ counts,
                                                   int *__restrict__ status, int cap) {
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint32_t s_patch[4][DS_W * DS_PP / 4 + 4];
+    __shared__ __attribute__((aligned(8))) uint16_t s_h[4][DS_W * DS_HC];
+    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wv_id;
     const int f = blockIdx.y;
     if (slot >= g.kp_total) return;
     int level, idx;
@@ -785,11 +815,70 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
     if (oi >= cap) return;
     const DLevel &L = g.lv[level];
     const int x = (int)(pos & 0xfff) + (ORBX_EDGE - 3), y = (int)((pos >> 12) & 0xfff) + (ORBX_EDGE - 3);
+    const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;
+    // ---- stage the 43x43 patch (rows y-21.., columns x-21..) as aligned dwords; `shift` = misalignment of x-21
+    uint32_t *patch = s_patch[wv_id];
+    uint16_t *hrow = s_h[wv_id];
+    const int px0 = x - DS_R, py0 = y - DS_R;
+    const int xa = px0 & ~3, shift = px0 & 3;
+    const bool interior = px0 >= 0 && py0 >= 0 && xa + DS_PP <= L.pitch && x + DS_R < L.pw && y + DS_R < L.ph;
+    if (interior) {
+        // 43 rows x 12 dwords = 516 dword loads: 8 wave steps of (16 lanes = 4 rows x ... ) -> lane = (row%.., dword)
+        const int dq = lane % 12, rq = lane / 12;     // lanes 0..59 active: 5 rows x 12 dwords per step
+        if (lane < 60) {
+            uint32_t tv[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int r = min(5 * k + rq, DS_W - 1);
+                tv[k] = *(const uint32_t *)(img + (long long)(py0 + r) * L.pitch + xa + 4 * dq);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int r = 5 * k + rq;
+                if (r < DS_W) patch[r * (DS_PP / 4) + dq] = tv[k];
+            }
+        }
+    } else {
+        // image edge: reflect-101 of the padded level, byte by byte (shift handled by writing at byte offset)
+        uint8_t *pb = (uint8_t *)patch;
+        for (int i = lane; i < DS_W * DS_W; i += 64) {
+            const int r = i / DS_W, c = i - r * DS_W;
+            const int sy = orbx_reflect101(py0 + r, L.ph), sx = orbx_reflect101(px0 + c, L.pw);
+            pb[r * DS_PP + shift + c] = img[(long long)sy * L.pitch + sx];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- row pass: h[r][c] for patch columns c+3 (c = 0..36 used), 4 outputs per item from 10 bytes
+    {
+        const uint8_t *pb = (const uint8_t *)patch + shift;
+        for (int i = lane; i < DS_W * (DS_HC / 4); i += 64) {
+            const int r = i / (DS_HC / 4), q4 = i - r * (DS_HC / 4);
+            const uint8_t *p = pb + r * DS_PP + 4 * q4;   // bytes p[0..9] = patch columns 4*q4 .. 4*q4+9
+            int bb[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) bb[k] = p[k];
+            uint32_t hv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                hv[j] = 18 * (bb[j] + bb[j + 6]) + 34 * (bb[j + 1] + bb[j + 5]) + 49 * (bb[j + 2] + bb[j + 4]) + 55 * bb[j + 3];
+            uint2 o;
+            o.x = hv[0] | (hv[1] << 16);
+            o.y = hv[2] | (hv[3] << 16);
+            *(uint2 *)(hrow + r * DS_HC + 4 * q4) = o;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- taps
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float angle = angle_deg * factorPI;
     const OrbxSinCos sc = orbx_sincosf_pinned(angle);
     const float a = sc.c, b = sc.s;
-    const uint8_t *center = blur + (long long)f * g.pyr_bytes + L.off + (long long)y * L.pitch + x;
+    const int wvec = L.pw & ~3;
+    const float k0 = 55.f / 65536.f, k1 = 49.f / 65536.f, k2 = 34.f / 65536.f, k3 = 18.f / 65536.f;
     const int pw4[4] = {pat.x, pat.y, pat.z, pat.w};
     int tv[8];
 #pragma unroll
@@ -807,7 +896,21 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
                 fx = px * a - py * b;
             }
             const int iy = (int)__builtin_rintf(fy), ix = (int)__builtin_rintf(fx);
-            tv[2 * r + s2] = center[iy * L.pitch + ix];
+            // blurred pixel (x+ix, y+iy): column pass over h rows (iy+21-3 .. iy+21+3), h column ix+18
+            const uint16_t *hp = hrow + (iy + DS_R - 3) * DS_HC + (ix + DS_R - 3);
+            const int r0 = hp[3 * DS_HC], r1 = hp[2 * DS_HC] + hp[4 * DS_HC], r2 = hp[1 * DS_HC] + hp[5 * DS_HC],
+                      r3 = hp[0] + hp[6 * DS_HC];
+            int o;
+            if (x + ix < wvec) {
+                float s0 = (float)r0 * k0 + 0.f;
+                s0 = s0 + (float)r1 * k1;
+                s0 = s0 + (float)r2 * k2;
+                s0 = s0 + (float)r3 * k3;
+                o = (int)__builtin_rintf(s0);
+            } else {
+                o = (55 * r0 + 49 * r1 + 34 * r2 + 18 * r3 + (1 << 15)) >> 16;
+            }
+            tv[2 * r + s2] = min(max(o, 0), 255);
         }
     }
     unsigned long long words[4];
@@ -836,53 +939,64 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
 // pair; bookkeeping of the search loops, e.g. :627-640).  One query per lane (8 dwords in VGPRs), train
 // descriptors staged through LDS in tiles and read as wave-wide broadcasts; v_xor + v_bcnt accumulate.
 // ------------------------------------------------------------------------------------------------
-#define MT_SPLIT 4
+#define MT_SPLIT 8
+#define MT_QPB 128  // queries per block: two per lane
 __global__ __launch_bounds__(64 * MT_SPLIT) void k_match(int npairs, const uint8_t *__restrict__ q,
                                                          const int *__restrict__ nq, long long q_stride,
                                                          const uint8_t *__restrict__ t, const int *__restrict__ nt,
                                                          long long t_stride, int *__restrict__ best_idx,
                                                          int *__restrict__ best_dist, int *__restrict__ second_dist,
                                                          int out_stride) {
-    // block = MT_SPLIT waves; every wave holds the same 64 queries (one per lane, 8 dwords in VGPRs) and scans
-    // its own quarter of the train set.  The train descriptor address is wave-uniform, so it is fetched through
-    // the scalar cache (s_load) and used as an SGPR operand of v_xor: no LDS staging, no barriers in the loop.
+    // block = MT_SPLIT waves; every wave holds the same 128 queries (two per lane, 16 dwords in VGPRs) and scans
+    // its own slice of the train set.  The train descriptor address is wave-uniform, so it is fetched through
+    // the scalar cache (s_load_dwordx8) and used as an SGPR operand of v_xor: no LDS staging, no barriers in the
+    // loop, and each scalar load feeds 128 distance evaluations.
     // key = dist << 20 | index: min(key) is the best match with the lowest index on ties; the second-smallest
     // key carries the second-best distance (counting duplicates), exactly the bookkeeping of the reference loops.
-    __shared__ uint32_t s_best[MT_SPLIT][64], s_second[MT_SPLIT][64];
+    __shared__ uint32_t s_best[MT_SPLIT][MT_QPB], s_second[MT_SPLIT][MT_QPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pr = blockIdx.y;
     const int NQ = nq[pr], NT = min(nt[pr], 1 << 20);
-    const int qi = blockIdx.x * 64 + lane;
-    if ((int)blockIdx.x * 64 >= NQ) return;
+    if ((int)blockIdx.x * MT_QPB >= NQ) return;
+    const int qi0 = blockIdx.x * MT_QPB + lane, qi1 = qi0 + 64;
     const uint4 *qp = (const uint4 *)(q + (long long)pr * q_stride);
     const uint4 *tp = (const uint4 *)(t + (long long)pr * t_stride);
-    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
-    if (qi < NQ) { qa = qp[2 * qi]; qb = qp[2 * qi + 1]; }
+    uint4 qa0 = make_uint4(0, 0, 0, 0), qb0 = qa0, qa1 = qa0, qb1 = qa0;
+    if (qi0 < NQ) { qa0 = qp[2 * qi0]; qb0 = qp[2 * qi0 + 1]; }
+    if (qi1 < NQ) { qa1 = qp[2 * qi1]; qb1 = qp[2 * qi1 + 1]; }
     const int chunk = (NT + MT_SPLIT - 1) / MT_SPLIT;
     const int j0 = __builtin_amdgcn_readfirstlane(w * chunk), j1 = min(NT, j0 + chunk);
-    uint32_t best = 0xffffffffu, second = 0xffffffffu;
-#pragma unroll 8
+    uint32_t best0 = 0xffffffffu, second0 = 0xffffffffu, best1 = 0xffffffffu, second1 = 0xffffffffu;
+#pragma unroll 4
     for (int j = j0; j < j1; ++j) {
         const uint4 ta = tp[2 * j], tb = tp[2 * j + 1];
-        const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
-                           __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
-        const uint32_t key = (d << 20) | (uint32_t)j;
-        second = min(second, max(best, key));
-        best = min(best, key);
+        const uint32_t d0 = __popc(qa0.x ^ ta.x) + __popc(qa0.y ^ ta.y) + __popc(qa0.z ^ ta.z) + __popc(qa0.w ^ ta.w) +
+                            __popc(qb0.x ^ tb.x) + __popc(qb0.y ^ tb.y) + __popc(qb0.z ^ tb.z) + __popc(qb0.w ^ tb.w);
+        const uint32_t d1 = __popc(qa1.x ^ ta.x) + __popc(qa1.y ^ ta.y) + __popc(qa1.z ^ ta.z) + __popc(qa1.w ^ ta.w) +
+                            __popc(qb1.x ^ tb.x) + __popc(qb1.y ^ tb.y) + __popc(qb1.z ^ tb.z) + __popc(qb1.w ^ tb.w);
+        const uint32_t key0 = (d0 << 20) | (uint32_t)j, key1 = (d1 << 20) | (uint32_t)j;
+        second0 = min(second0, max(best0, key0));
+        best0 = min(best0, key0);
+        second1 = min(second1, max(best1, key1));
+        best1 = min(best1, key1);
     }
-    s_best[w][lane] = best;
-    s_second[w][lane] = second;
+    s_best[w][lane] = best0; s_second[w][lane] = second0;
+    s_best[w][lane + 64] = best1; s_second[w][lane + 64] = second1;
     __syncthreads();
-    if (w == 0 && qi < NQ) {
+    if (w < 2) {
+        const int slot = lane + 64 * w, qi = blockIdx.x * MT_QPB + slot;
+        if (qi < NQ) {
+            uint32_t best = s_best[0][slot], second = s_second[0][slot];
 #pragma unroll
-        for (int k = 1; k < MT_SPLIT; ++k) {
-            const uint32_t bk = s_best[k][lane], sk = s_second[k][lane];
-            second = min(min(second, sk), max(best, bk));
-            best = min(best, bk);
+            for (int k = 1; k < MT_SPLIT; ++k) {
+                const uint32_t bk = s_best[k][slot], sk = s_second[k][slot];
+                second = min(min(second, sk), max(best, bk));
+                best = min(best, bk);
+            }
+            const long long o = (long long)pr * out_stride + qi;
+            best_idx[o] = best == 0xffffffffu ? -1 : (int)(best & 0xfffffu);
+            best_dist[o] = best == 0xffffffffu ? 0x7fffffff : (int)(best >> 20);
+            second_dist[o] = second == 0xffffffffu ? 0x7fffffff : (int)(second >> 20);
         }
-        const long long o = (long long)pr * out_stride + qi;
-        best_idx[o] = best == 0xffffffffu ? -1 : (int)(best & 0xfffffu);
-        best_dist[o] = best == 0xffffffffu ? 0x7fffffff : (int)(best >> 20);
-        second_dist[o] = second == 0xffffffffu ? 0x7fffffff : (int)(second >> 20);
     }
 }
 
@@ -1043,11 +1157,10 @@ void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cell
                       int *cell_count, int max_cw, int max_ch) {
     if (g.ncells == 0) return;
     const int tp = (max_cw + 3 + 3) & ~3;           // +3: dword-alignment shift of the tile origin
-    const int lcap = (max_cw - 6) * (max_ch - 6);   // every interior pixel could be a corner
-    const int scap = ((max_cw - 6 + 1) / 2) * ((max_ch - 6 + 1) / 2);  // strict 3x3 maxima: <= 1 per 2x2 block
-    const size_t smem = (size_t)2 * max_ch * tp + 3 * (size_t)((2 * lcap + 3) & ~3) + 4 * (size_t)scap;
-    hipLaunchKernelGGL(k_fast_cells, dim3(g.ncells, B), dim3(64), smem, s, g, cells, pyr, cand, cell_count, tp,
-                       max_ch, lcap);
+    const int lcap = (max_cw - 6) * (max_ch - 6);   // every interior pixel could pass the pre-test
+    const size_t smem = (size_t)2 * max_ch * tp + 2 * (size_t)((2 * lcap + 3) & ~3);
+    hipLaunchKernelGGL(k_fast_cells, dim3((g.ncells + FAST_CPW - 1) / FAST_CPW, B), dim3(64), smem, s, g, cells, pyr, cand,
+                       cell_count, tp, max_ch, lcap);
 }
 void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
                           const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,
@@ -1066,17 +1179,17 @@ void orbx_launch_orient(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr
 void orbx_launch_blur(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, uint8_t *blur) {
     hipLaunchKernelGGL(k_blur, dim3(g.blur_tiles, B), dim3(256), 0, s, g, pyr, blur);
 }
-void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *blur, const uint32_t *lvl_kp,
+void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
                           const int *lvl_count, const float *lvl_angle, orbx_keypoint *kps, uint8_t *desc,
                           int *counts, int *status, int cap) {
-    hipLaunchKernelGGL(k_describe, dim3((g.kp_total + 3) / 4, B), dim3(256), 0, s, g, blur, lvl_kp, lvl_count,
+    hipLaunchKernelGGL(k_describe, dim3((g.kp_total + 3) / 4, B), dim3(256), 0, s, g, pyr, lvl_kp, lvl_count,
                        lvl_angle, kps, desc, counts, status, cap);
 }
 void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,
                        const uint8_t *t, const int *nt, long long t_stride, int *best_idx, int *best_dist,
                        int *second_dist, int out_stride) {
     if (npairs <= 0 || max_nq <= 0) return;
-    hipLaunchKernelGGL(k_match, dim3((max_nq + 63) / 64, npairs), dim3(64 * MT_SPLIT), 0, s, npairs, q, nq, q_stride, t, nt,
+    hipLaunchKernelGGL(k_match, dim3((max_nq + MT_QPB - 1) / MT_QPB, npairs), dim3(64 * MT_SPLIT), 0, s, npairs, q, nq, q_stride, t, nt,
                        t_stride, best_idx, best_dist, second_dist, out_stride);
 }
 void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *dist) {

@@ -18,7 +18,7 @@ void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *
 void orbx_launch_orient(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
                         const int *lvl_count, float *lvl_angle);
 void orbx_launch_blur(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, uint8_t *blur);
-void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *blur, const uint32_t *lvl_kp,
+void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
                           const int *lvl_count, const float *lvl_angle, orbx_keypoint *kps, uint8_t *desc,
                           int *counts, int *status, int cap);
 void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,
