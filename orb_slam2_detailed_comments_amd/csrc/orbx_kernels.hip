@@ -122,7 +122,8 @@ __device__ __forceinline__ void orbx_wave_sync() {
 
 __global__ __launch_bounds__(64, 5) void k_fast_cells(DGeom g, const OrbxCell *__restrict__ cells,
                                                    const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
-                                                   int *__restrict__ cell_count, int FAST_TP, int rows, int lcap) {
+                                                   int *__restrict__ cell_count, int FAST_TP, int rows, int lcap,
+                                                   int cell_begin, int cell_end) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
     const int lcap_b = (2 * lcap + 3) & ~3;
     uint32_t *s_tile = (uint32_t *)fast_smem;
@@ -138,8 +139,8 @@ __global__ __launch_bounds__(64, 5) void k_fast_cells(DGeom g, const OrbxCell *_
     const int ro[16] = {3 * FAST_TP,      3 * FAST_TP + 1,  2 * FAST_TP + 2,  FAST_TP + 3, 3,  -FAST_TP + 3,
                         -2 * FAST_TP + 2, -3 * FAST_TP + 1, -3 * FAST_TP,     -3 * FAST_TP - 1, -2 * FAST_TP - 2,
                         -FAST_TP - 3,     -3,               FAST_TP - 3,      2 * FAST_TP - 2,  3 * FAST_TP - 1};
-    const int cell0 = blockIdx.x * FAST_CPW;
-    const int ncell = min(FAST_CPW, g.ncells - cell0);
+    const int cell0 = cell_begin + blockIdx.x * FAST_CPW;
+    const int ncell = min(FAST_CPW, cell_end - cell0);
     uint32_t tv[FAST_PF];
     // ---- prefetch of the first tile (all loads in flight before anything waits on them)
     OrbxCell c = cells[cell0];
@@ -775,7 +776,7 @@ __constant__ int4 c_pattern_lane[64];
 // same as k_blur's (8-bit kernel, float column path for x < (w & ~3), integer tail), so descriptors are unchanged.
 #define DS_R 21                 // patch radius: 18 (taps) + 3 (filter support)
 #define DS_W (2 * DS_R + 1)     // 43
-#define DS_PP 48                // LDS patch pitch in bytes (43 + up to 3 alignment shift, multiple of 4)
+#define DS_PP 44                // LDS patch pitch in bytes (11 dwords; rows start dword-aligned in LDS)
 #define DS_HC 40                // row-pass outputs per row (37 needed, computed in groups of 4)
 __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
                                                   const uint32_t *__restrict__ lvl_kp,
@@ -816,21 +817,20 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
     const DLevel &L = g.lv[level];
     const int x = (int)(pos & 0xfff) + (ORBX_EDGE - 3), y = (int)((pos >> 12) & 0xfff) + (ORBX_EDGE - 3);
     const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;
-    // ---- stage the 43x43 patch (rows y-21.., columns x-21..) as aligned dwords; `shift` = misalignment of x-21
+    // ---- stage the 43x43 patch (rows y-21.., columns x-21..): 11 dwords per row, loaded from the (generally
+    // unaligned) byte address so that every LDS row starts dword-aligned
     uint32_t *patch = s_patch[wv_id];
     uint16_t *hrow = s_h[wv_id];
     const int px0 = x - DS_R, py0 = y - DS_R;
-    const int xa = px0 & ~3, shift = px0 & 3;
-    const bool interior = px0 >= 0 && py0 >= 0 && xa + DS_PP <= L.pitch && x + DS_R < L.pw && y + DS_R < L.ph;
+    const bool interior = px0 >= 0 && py0 >= 0 && px0 + DS_PP <= L.pitch && x + DS_R < L.pw && y + DS_R < L.ph;
     if (interior) {
-        // 43 rows x 12 dwords = 516 dword loads: 8 wave steps of (16 lanes = 4 rows x ... ) -> lane = (row%.., dword)
-        const int dq = lane % 12, rq = lane / 12;     // lanes 0..59 active: 5 rows x 12 dwords per step
-        if (lane < 60) {
+        const int dq = lane % 11, rq = lane / 11;     // lanes 0..54 active: 5 rows x 11 dwords per step
+        if (lane < 55) {
             uint32_t tv[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const int r = min(5 * k + rq, DS_W - 1);
-                tv[k] = *(const uint32_t *)(img + (long long)(py0 + r) * L.pitch + xa + 4 * dq);
+                __builtin_memcpy(&tv[k], img + (long long)(py0 + r) * L.pitch + px0 + 4 * dq, 4);
             }
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
@@ -839,35 +839,34 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
             }
         }
     } else {
-        // image edge: reflect-101 of the padded level, byte by byte (shift handled by writing at byte offset)
+        // image edge: reflect-101 of the padded level, byte by byte
         uint8_t *pb = (uint8_t *)patch;
         for (int i = lane; i < DS_W * DS_W; i += 64) {
             const int r = i / DS_W, c = i - r * DS_W;
             const int sy = orbx_reflect101(py0 + r, L.ph), sx = orbx_reflect101(px0 + c, L.pw);
-            pb[r * DS_PP + shift + c] = img[(long long)sy * L.pitch + sx];
+            pb[r * DS_PP + c] = img[(long long)sy * L.pitch + sx];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- row pass: h[r][c] for patch columns c+3 (c = 0..36 used), 4 outputs per item from 10 bytes
-    {
-        const uint8_t *pb = (const uint8_t *)patch + shift;
-        for (int i = lane; i < DS_W * (DS_HC / 4); i += 64) {
-            const int r = i / (DS_HC / 4), q4 = i - r * (DS_HC / 4);
-            const uint8_t *p = pb + r * DS_PP + 4 * q4;   // bytes p[0..9] = patch columns 4*q4 .. 4*q4+9
-            int bb[10];
+    // ---- row pass: h[r][c] for patch columns c+3 (c = 0..36 used); 4 outputs per item from 3 aligned dwords via
+    // v_alignbyte + v_dot4_u32_u8 with the packed 8-bit kernel {18,34,49,55 | 49,34,18,0}
+    for (int i = lane; i < DS_W * (DS_HC / 4); i += 64) {
+        const int r = i / (DS_HC / 4), q4 = i - r * (DS_HC / 4);
+        const uint32_t *w = patch + r * (DS_PP / 4) + q4;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24), KHI = 49u | (34u << 8) | (18u << 16);
+        uint32_t hv[4];
+        hv[0] = __builtin_amdgcn_udot4(w0, KLO, __builtin_amdgcn_udot4(w1, KHI, 0u, false), false);
 #pragma unroll
-            for (int k = 0; k < 10; ++k) bb[k] = p[k];
-            uint32_t hv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                hv[j] = 18 * (bb[j] + bb[j + 6]) + 34 * (bb[j + 1] + bb[j + 5]) + 49 * (bb[j + 2] + bb[j + 4]) + 55 * bb[j + 3];
-            uint2 o;
-            o.x = hv[0] | (hv[1] << 16);
-            o.y = hv[2] | (hv[3] << 16);
-            *(uint2 *)(hrow + r * DS_HC + 4 * q4) = o;
-        }
+        for (int j = 1; j < 4; ++j)
+            hv[j] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, j), KLO,
+                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, j), KHI, 0u, false), false);
+        uint2 o;
+        o.x = hv[0] | (hv[1] << 16);   // each <= 255 * 257 = 65535
+        o.y = hv[2] | (hv[3] << 16);
+        *(uint2 *)(hrow + r * DS_HC + 4 * q4) = o;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1154,13 +1153,13 @@ void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, con
     hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, g, level, taps, pyr);
 }
 void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint8_t *pyr, uint2 *cand,
-                      int *cell_count, int max_cw, int max_ch) {
-    if (g.ncells == 0) return;
+                      int *cell_count, int max_cw, int max_ch, int cell_begin, int cell_end) {
+    if (cell_end <= cell_begin) return;
     const int tp = (max_cw + 3 + 3) & ~3;           // +3: dword-alignment shift of the tile origin
     const int lcap = (max_cw - 6) * (max_ch - 6);   // every interior pixel could pass the pre-test
     const size_t smem = (size_t)2 * max_ch * tp + 2 * (size_t)((2 * lcap + 3) & ~3);
-    hipLaunchKernelGGL(k_fast_cells, dim3((g.ncells + FAST_CPW - 1) / FAST_CPW, B), dim3(64), smem, s, g, cells, pyr, cand,
-                       cell_count, tp, max_ch, lcap);
+    hipLaunchKernelGGL(k_fast_cells, dim3((cell_end - cell_begin + FAST_CPW - 1) / FAST_CPW, B), dim3(64), smem, s, g, cells,
+                       pyr, cand, cell_count, tp, max_ch, lcap, cell_begin, cell_end);
 }
 void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
                           const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,
