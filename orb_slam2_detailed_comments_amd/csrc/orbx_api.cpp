@@ -53,6 +53,7 @@ struct orbx_handle {
     int out_cap = 0;
     int last_batch = 0;
     int mk_w = 0, mk_h = 0, mk_total = 0;   // orbx_max_keypoints cache
+    void *d_match_ws = nullptr; size_t match_ws_bytes = 0;   // partial (best, second) keys of k_match
     bool blur_valid = false;                // d_blur holds the blurred pyramid of the last batch
     // profiling
     uint32_t prof_mask = 0;
@@ -247,6 +248,7 @@ extern "C" void orbx_destroy(orbx_handle *h) {
         prof_drain(h);
         for (auto e : h->pool) hipEventDestroy(e);
         free_geometry_buffers(h);
+        hipFree(h->d_match_ws);
         hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_ustatus);
         if (h->own_stream) hipStreamDestroy(h->own_stream);
     }
@@ -311,8 +313,7 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
       orbx_launch_quadtree(s, g, B, h->d_cells, h->d_cand, h->d_cell_count, h->d_dense, h->d_cand_count, h->d_lvl_kp,
                            h->d_lvl_count, d_status, h->d_knode,
                            h->ncap, h->lds_keys); }
-    { ProfScope ps(h, ORBX_K_ORIENT);
-      orbx_launch_orient(s, g, B, h->d_pyr, h->d_lvl_kp, h->d_lvl_count, h->d_lvl_angle); }
+    // orientation (IC_Angle) is computed inside k_describe from the same LDS patch the descriptor uses
     h->blur_valid = false;  // the Gaussian is fused into k_describe; the full blurred image is only built on request
     { ProfScope ps(h, ORBX_K_DESC);
       orbx_launch_describe(s, g, B, h->d_pyr, h->d_lvl_kp, h->d_lvl_count, h->d_lvl_angle, d_kps, d_desc, d_counts,
@@ -516,9 +517,16 @@ extern "C" orbx_status orbx_match_bruteforce_device(orbx_handle *h, int npairs, 
     if (npairs <= 0 || !d_q || !d_t || !d_nq || !d_nt || !d_best_idx || !d_best_dist || !d_second_dist || out_stride <= 0)
         return fail(ORBX_BAD_ARGUMENT, "bad argument");
     HIPCHK(hipSetDevice(h->dev));
+    const size_t need = orbx_match_workspace_bytes(npairs, out_stride);
+    if (need > h->match_ws_bytes) {   // grows only when a larger problem than ever before arrives
+        HIPCHK(hipStreamSynchronize(h->stream));
+        hipFree(h->d_match_ws); h->d_match_ws = nullptr; h->match_ws_bytes = 0;
+        HIPCHK(hipMalloc(&h->d_match_ws, need));
+        h->match_ws_bytes = need;
+    }
     { ProfScope ps(h, ORBX_K_MATCH);
       orbx_launch_match(h->stream, npairs, out_stride, d_q, d_nq, q_stride, d_t, d_nt, t_stride, d_best_idx, d_best_dist,
-                        d_second_dist, out_stride); }
+                        d_second_dist, out_stride, h->d_match_ws); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
     return ORBX_OK;

@@ -16,20 +16,29 @@
 __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restrict__ imgs, int W, int H, int stride,
                                                 long long frame_stride, uint8_t *__restrict__ pyr) {
     const DLevel &L = g.lv[0];
-    const int X = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int Y = blockIdx.y;
+    const int X = (blockIdx.x * 64 + threadIdx.x) * 16;   // block = 64 x 4 threads, thread = 16 pixels (one 16-B store)
+    const int Y = blockIdx.y * 4 + threadIdx.y;
     const int f = blockIdx.z;
-    if (X >= L.pw) return;
+    if (X >= L.pw || Y >= L.ph) return;
     const uint8_t *src = imgs + (long long)f * frame_stride + (long long)orbx_reflect101(Y - ORBX_EDGE, H) * stride;
-    uint32_t v = 0;
+    uint4 v;
+    if (X >= ORBX_EDGE && X + 15 - ORBX_EDGE < W) {
+        __builtin_memcpy(&v, src + (X - ORBX_EDGE), 16);   // interior: one (unaligned) 16-byte load
+    } else {
+        uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int x = X + i;
-        uint32_t p = 0;
-        if (x < L.pw) p = src[orbx_reflect101(x - ORBX_EDGE, W)];
-        v |= p << (8 * i);
+        for (int q = 0; q < 4; ++q) {
+            w[q] = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = X + 4 * q + i;
+                const uint32_t p = x < L.pw ? src[orbx_reflect101(x - ORBX_EDGE, W)] : 0u;
+                w[q] |= p << (8 * i);
+            }
+        }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    *(uint32_t *)(pyr + (long long)f * g.pyr_bytes + L.off + (long long)Y * L.pitch + X) = v;
+    *(uint4 *)(pyr + (long long)f * g.pyr_bytes + L.off + (long long)Y * L.pitch + X) = v;   // pitch % 64 == 0
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -781,7 +790,7 @@ __constant__ int4 c_pattern_lane[64];
 __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
                                                   const uint32_t *__restrict__ lvl_kp,
                                                   const int *__restrict__ lvl_count,
-                                                  const float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
+                                                  float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int *__restrict__ counts,
                                                   int *__restrict__ status, int cap) {
     __shared__ uint32_t s_patch[4][DS_W * DS_PP / 4 + 4];
@@ -792,9 +801,8 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
     if (slot >= g.kp_total) return;
     int level, idx;
     orbx_slot_to_level(g, slot, level, idx);
-    // independent loads first: position, angle, this lane's 8 pattern points, the per-level counts
+    // independent loads first: position, this lane's 8 pattern points, the per-level counts
     const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];
-    const float angle_deg = lvl_angle[(long long)f * g.kp_total + slot];
     const int4 pat = c_pattern_lane[lane];
     const int *lc = lvl_count + f * g.nlevels;
     int before = 0, total = 0, mine = 0;
@@ -850,6 +858,29 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- orientation (IC_Angle, reference src/ORBextractor.cc:104-161) from the staged UN-blurred patch: lanes 0-31
+    // take the row +v, lanes 32-63 the row -v; integer moments reduced across the wave; fastAtan2 on every lane
+    float angle_deg;
+    {
+        const uint8_t *pc = (const uint8_t *)patch + DS_R * DS_PP + DS_R;   // the keypoint itself
+        const int u = (lane & 31) - ORBX_HALF_PATCH;                        // -15..16
+        const int sgn = lane < 32 ? 1 : -1;
+        int vals[ORBX_HALF_PATCH + 1];
+#pragma unroll
+        for (int v = 0; v <= ORBX_HALF_PATCH; ++v) vals[v] = pc[u + sgn * v * DS_PP];
+        int m10 = lane < 31 ? u * vals[0] : 0, m01 = 0;
+#pragma unroll
+        for (int v = 1; v <= ORBX_HALF_PATCH; ++v) {
+            const int d = g.umax[v];
+            const int val = (u >= -d && u <= d) ? vals[v] : 0;
+            m10 += u * val;
+            m01 += sgn * v * val;
+        }
+        m10 = orbx_wave_sum(m10);
+        m01 = orbx_wave_sum(m01);
+        angle_deg = orbx_fast_atan2((float)m01, (float)m10);
+        if (lane == 0) lvl_angle[(long long)f * g.kp_total + slot] = angle_deg;
+    }
     // ---- row pass: h[r][c] for patch columns c+3 (c = 0..36 used); 4 outputs per item from 3 aligned dwords via
     // v_alignbyte + v_dot4_u32_u8 with the packed 8-bit kernel {18,34,49,55 | 49,34,18,0}
     for (int i = lane; i < DS_W * (DS_HC / 4); i += 64) {
@@ -938,65 +969,81 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
 // pair; bookkeeping of the search loops, e.g. :627-640).  One query per lane (8 dwords in VGPRs), train
 // descriptors staged through LDS in tiles and read as wave-wide broadcasts; v_xor + v_bcnt accumulate.
 // ------------------------------------------------------------------------------------------------
-#define MT_SPLIT 8
-#define MT_QPB 128  // queries per block: two per lane
-__global__ __launch_bounds__(64 * MT_SPLIT) void k_match(int npairs, const uint8_t *__restrict__ q,
-                                                         const int *__restrict__ nq, long long q_stride,
-                                                         const uint8_t *__restrict__ t, const int *__restrict__ nt,
-                                                         long long t_stride, int *__restrict__ best_idx,
-                                                         int *__restrict__ best_dist, int *__restrict__ second_dist,
-                                                         int out_stride) {
-    // block = MT_SPLIT waves; every wave holds the same 128 queries (two per lane, 16 dwords in VGPRs) and scans
-    // its own slice of the train set.  The train descriptor address is wave-uniform, so it is fetched through
-    // the scalar cache (s_load_dwordx8) and used as an SGPR operand of v_xor: no LDS staging, no barriers in the
-    // loop, and each scalar load feeds 128 distance evaluations.
+#define MT_SPLIT 16     // train set split over blockIdx.y (8192 waves at 64 pairs x 1000 x 1000); partials merged by k_match_merge
+#define MT_WAVES 8      // waves per block
+#define MT_QPB (MT_WAVES * 128)   // queries per block: two per lane
+#define MT_TILE 64      // train descriptors per LDS tile (2 KB)
+__global__ __launch_bounds__(64 * MT_WAVES) void k_match(const uint8_t *__restrict__ q, const int *__restrict__ nq,
+                                                         long long q_stride, const uint8_t *__restrict__ t,
+                                                         const int *__restrict__ nt, long long t_stride,
+                                                         uint2 *__restrict__ partial, int out_stride) {
+    // block = 8 waves = 1024 queries (two per lane, 16 dwords in VGPRs) against one quarter of the train set.
+    // Train descriptors are staged through LDS in 4 KB tiles (double buffered) and read back as wave-wide
+    // broadcasts, so one global read of a train descriptor feeds 1024 distance evaluations.
     // key = dist << 20 | index: min(key) is the best match with the lowest index on ties; the second-smallest
     // key carries the second-best distance (counting duplicates), exactly the bookkeeping of the reference loops.
-    __shared__ uint32_t s_best[MT_SPLIT][MT_QPB], s_second[MT_SPLIT][MT_QPB];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pr = blockIdx.y;
+    __shared__ uint4 s_t[2][MT_TILE * 2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pr = blockIdx.z, sp = blockIdx.y;
     const int NQ = nq[pr], NT = min(nt[pr], 1 << 20);
     if ((int)blockIdx.x * MT_QPB >= NQ) return;
-    const int qi0 = blockIdx.x * MT_QPB + lane, qi1 = qi0 + 64;
+    const int qi0 = blockIdx.x * MT_QPB + w * 128 + lane, qi1 = qi0 + 64;
     const uint4 *qp = (const uint4 *)(q + (long long)pr * q_stride);
     const uint4 *tp = (const uint4 *)(t + (long long)pr * t_stride);
     uint4 qa0 = make_uint4(0, 0, 0, 0), qb0 = qa0, qa1 = qa0, qb1 = qa0;
     if (qi0 < NQ) { qa0 = qp[2 * qi0]; qb0 = qp[2 * qi0 + 1]; }
     if (qi1 < NQ) { qa1 = qp[2 * qi1]; qb1 = qp[2 * qi1 + 1]; }
     const int chunk = (NT + MT_SPLIT - 1) / MT_SPLIT;
-    const int j0 = __builtin_amdgcn_readfirstlane(w * chunk), j1 = min(NT, j0 + chunk);
+    const int j0 = sp * chunk, j1 = min(NT, j0 + chunk);
     uint32_t best0 = 0xffffffffu, second0 = 0xffffffffu, best1 = 0xffffffffu, second1 = 0xffffffffu;
-#pragma unroll 4
-    for (int j = j0; j < j1; ++j) {
-        const uint4 ta = tp[2 * j], tb = tp[2 * j + 1];
-        const uint32_t d0 = __popc(qa0.x ^ ta.x) + __popc(qa0.y ^ ta.y) + __popc(qa0.z ^ ta.z) + __popc(qa0.w ^ ta.w) +
-                            __popc(qb0.x ^ tb.x) + __popc(qb0.y ^ tb.y) + __popc(qb0.z ^ tb.z) + __popc(qb0.w ^ tb.w);
-        const uint32_t d1 = __popc(qa1.x ^ ta.x) + __popc(qa1.y ^ ta.y) + __popc(qa1.z ^ ta.z) + __popc(qa1.w ^ ta.w) +
-                            __popc(qb1.x ^ tb.x) + __popc(qb1.y ^ tb.y) + __popc(qb1.z ^ tb.z) + __popc(qb1.w ^ tb.w);
-        const uint32_t key0 = (d0 << 20) | (uint32_t)j, key1 = (d1 << 20) | (uint32_t)j;
-        second0 = min(second0, max(best0, key0));
-        best0 = min(best0, key0);
-        second1 = min(second1, max(best1, key1));
-        best1 = min(best1, key1);
-    }
-    s_best[w][lane] = best0; s_second[w][lane] = second0;
-    s_best[w][lane + 64] = best1; s_second[w][lane + 64] = second1;
+    // first tile
+    if (tid < 2 * MT_TILE && j0 + (tid >> 1) < j1) s_t[0][tid] = tp[2 * j0 + tid];
     __syncthreads();
-    if (w < 2) {
-        const int slot = lane + 64 * w, qi = blockIdx.x * MT_QPB + slot;
-        if (qi < NQ) {
-            uint32_t best = s_best[0][slot], second = s_second[0][slot];
-#pragma unroll
-            for (int k = 1; k < MT_SPLIT; ++k) {
-                const uint32_t bk = s_best[k][slot], sk = s_second[k][slot];
-                second = min(min(second, sk), max(best, bk));
-                best = min(best, bk);
-            }
-            const long long o = (long long)pr * out_stride + qi;
-            best_idx[o] = best == 0xffffffffu ? -1 : (int)(best & 0xfffffu);
-            best_dist[o] = best == 0xffffffffu ? 0x7fffffff : (int)(best >> 20);
-            second_dist[o] = second == 0xffffffffu ? 0x7fffffff : (int)(second >> 20);
+    int buf = 0;
+    for (int jt = j0; jt < j1; jt += MT_TILE) {
+        const int n = min(MT_TILE, j1 - jt);
+        const int jn = jt + MT_TILE;
+        uint4 pre = make_uint4(0, 0, 0, 0);
+        const bool do_pre = tid < 2 * MT_TILE && jn + (tid >> 1) < j1;
+        if (do_pre) pre = tp[2 * jn + tid];          // next tile in flight while this one is consumed
+        const uint4 *tile = s_t[buf];
+#pragma unroll 4
+        for (int j = 0; j < n; ++j) {
+            const uint4 ta = tile[2 * j], tb = tile[2 * j + 1];
+            const uint32_t d0 = __popc(qa0.x ^ ta.x) + __popc(qa0.y ^ ta.y) + __popc(qa0.z ^ ta.z) + __popc(qa0.w ^ ta.w) +
+                                __popc(qb0.x ^ tb.x) + __popc(qb0.y ^ tb.y) + __popc(qb0.z ^ tb.z) + __popc(qb0.w ^ tb.w);
+            const uint32_t d1 = __popc(qa1.x ^ ta.x) + __popc(qa1.y ^ ta.y) + __popc(qa1.z ^ ta.z) + __popc(qa1.w ^ ta.w) +
+                                __popc(qb1.x ^ tb.x) + __popc(qb1.y ^ tb.y) + __popc(qb1.z ^ tb.z) + __popc(qb1.w ^ tb.w);
+            const uint32_t key0 = (d0 << 20) | (uint32_t)(jt + j), key1 = (d1 << 20) | (uint32_t)(jt + j);
+            second0 = min(second0, max(best0, key0));
+            best0 = min(best0, key0);
+            second1 = min(second1, max(best1, key1));
+            best1 = min(best1, key1);
         }
+        if (do_pre) s_t[buf ^ 1][tid] = pre;
+        __syncthreads();
+        buf ^= 1;
     }
+    uint2 *po = partial + ((long long)pr * MT_SPLIT + sp) * out_stride;
+    if (qi0 < NQ) po[qi0] = make_uint2(best0, second0);
+    if (qi1 < NQ) po[qi1] = make_uint2(best1, second1);
+}
+
+__global__ __launch_bounds__(256) void k_match_merge(const int *__restrict__ nq, const uint2 *__restrict__ partial,
+                                                     int *__restrict__ best_idx, int *__restrict__ best_dist,
+                                                     int *__restrict__ second_dist, int out_stride) {
+    const int pr = blockIdx.y, qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq[pr]) return;
+    uint32_t best = 0xffffffffu, second = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < MT_SPLIT; ++k) {
+        const uint2 p = partial[((long long)pr * MT_SPLIT + k) * out_stride + qi];
+        second = min(min(second, p.y), max(best, p.x));
+        best = min(best, p.x);
+    }
+    const long long o = (long long)pr * out_stride + qi;
+    best_idx[o] = best == 0xffffffffu ? -1 : (int)(best & 0xfffffu);
+    best_dist[o] = best == 0xffffffffu ? 0x7fffffff : (int)(best >> 20);
+    second_dist[o] = second == 0xffffffffu ? 0x7fffffff : (int)(second >> 20);
 }
 
 // full distance matrix (uint16) for host-side sequential policies
@@ -1144,8 +1191,8 @@ void orbx_launch_clear(hipStream_t s, int *a, int na, int *b, int nb, int *c, in
 void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
                         long long frame_stride, uint8_t *pyr) {
     const DLevel &L = g.lv[0];
-    dim3 grid((L.pitch / 4 + 255) / 256, L.ph, B);
-    hipLaunchKernelGGL(k_pyr_l0, grid, dim3(256), 0, s, g, imgs, W, H, stride, frame_stride, pyr);
+    dim3 grid((L.pw + 1023) / 1024, (L.ph + 3) / 4, B);
+    hipLaunchKernelGGL(k_pyr_l0, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr);
 }
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr) {
     const DLevel &L = g.lv[level];
@@ -1179,17 +1226,20 @@ void orbx_launch_blur(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, 
     hipLaunchKernelGGL(k_blur, dim3(g.blur_tiles, B), dim3(256), 0, s, g, pyr, blur);
 }
 void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
-                          const int *lvl_count, const float *lvl_angle, orbx_keypoint *kps, uint8_t *desc,
+                          const int *lvl_count, float *lvl_angle, orbx_keypoint *kps, uint8_t *desc,
                           int *counts, int *status, int cap) {
     hipLaunchKernelGGL(k_describe, dim3((g.kp_total + 3) / 4, B), dim3(256), 0, s, g, pyr, lvl_kp, lvl_count,
                        lvl_angle, kps, desc, counts, status, cap);
 }
+size_t orbx_match_workspace_bytes(int npairs, int out_stride) { return (size_t)npairs * MT_SPLIT * out_stride * sizeof(uint2); }
 void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,
                        const uint8_t *t, const int *nt, long long t_stride, int *best_idx, int *best_dist,
-                       int *second_dist, int out_stride) {
+                       int *second_dist, int out_stride, void *workspace) {
     if (npairs <= 0 || max_nq <= 0) return;
-    hipLaunchKernelGGL(k_match, dim3((max_nq + MT_QPB - 1) / MT_QPB, npairs), dim3(64 * MT_SPLIT), 0, s, npairs, q, nq, q_stride, t, nt,
-                       t_stride, best_idx, best_dist, second_dist, out_stride);
+    hipLaunchKernelGGL(k_match, dim3((max_nq + MT_QPB - 1) / MT_QPB, MT_SPLIT, npairs), dim3(64 * MT_WAVES), 0, s, q, nq,
+                       q_stride, t, nt, t_stride, (uint2 *)workspace, out_stride);
+    hipLaunchKernelGGL(k_match_merge, dim3((max_nq + 255) / 256, npairs), dim3(256), 0, s, nq, (const uint2 *)workspace,
+                       best_idx, best_dist, second_dist, out_stride);
 }
 void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *dist) {
     const long long n = (long long)nq * nt;

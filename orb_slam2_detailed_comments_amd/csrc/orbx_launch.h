@@ -19,11 +19,12 @@ void orbx_launch_orient(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr
                         const int *lvl_count, float *lvl_angle);
 void orbx_launch_blur(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, uint8_t *blur);
 void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
-                          const int *lvl_count, const float *lvl_angle, orbx_keypoint *kps, uint8_t *desc,
+                          const int *lvl_count, float *lvl_angle, orbx_keypoint *kps, uint8_t *desc,
                           int *counts, int *status, int cap);
 void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,
                        const uint8_t *t, const int *nt, long long t_stride, int *best_idx, int *best_dist,
-                       int *second_dist, int out_stride);
+                       int *second_dist, int out_stride, void *workspace);
+size_t orbx_match_workspace_bytes(int npairs, int out_stride);
 void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *dist);
 
 void orbx_launch_stereo(hipStream_t s, const OrbxStereoGeom &sg, const orbx_keypoint *kL, const uint8_t *dL, int nL,
