@@ -51,6 +51,19 @@ def algorithmic_bytes(ex, w, h, n_kp):
     }
 
 
+def measured_traffic(kernel, B, W, H, NF):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 calibration in tools/fetch_calib.hip).
+    None when the committed counters were taken on another workload."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if (t["batch"], t["width"], t["height"], t["nfeatures"]) != (B, W, H, NF):
+            return None
+        return int(t["kernels"][kernel]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(frames, nfeatures, budget_s=20.0):
     """single-thread CPU oracle (port of the reference path) on a bounded sample of the same frames"""
     import oracle
@@ -73,12 +86,15 @@ def cpu_baseline(frames, nfeatures, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent extract+match pipelines per GPU, used round-robin (3 adds ~10 %% throughput but "
+                         "overlapping kernels blur the per-kernel timing; default 1 keeps the roofline accounting clean)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also print a per-kernel table to stderr")
     args = ap.parse_args()
@@ -95,50 +111,74 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, W, H, NF = args.batch, args.width, args.height, args.nfeatures
+    NS = max(1, args.streams)
     frames = synth.stream(W, H, B, stream_id=100 + rank)
     d_imgs = torch.from_numpy(frames).to(dev)
-    ex = ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B, device=local_rank)
     L = _capi.lib()
+    # NS independent pipelines (handle + HIP stream + result buffers), used round-robin: while one batch is in its
+    # latency-bound tail (quadtree, small pyramid levels) the next batch's streaming kernels fill the chip.
+    exs = [ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B, device=local_rank) for _ in range(NS)]
+    ex = exs[0]
     cap = ex.max_keypoints(W, H)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+    for e, st in zip(exs, streams):
+        e.set_stream(st.cuda_stream)
     # slot 0 of the result buffers carries the last frame of the previous step (match t vs t-1)
-    d_kps = torch.zeros((B + 1, cap * 28), dtype=torch.uint8, device=dev)
-    d_desc = torch.zeros((B + 1, cap * 32), dtype=torch.uint8, device=dev)
-    d_counts = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_midx = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-    d_mbest = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-    d_msecond = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    ex.set_stream(stream.cuda_stream)
+    bufs = []
+    for _ in range(NS):
+        bufs.append(dict(
+            kps=torch.zeros((B + 1, cap * 28), dtype=torch.uint8, device=dev),
+            desc=torch.zeros((B + 1, cap * 32), dtype=torch.uint8, device=dev),
+            counts=torch.zeros(B + 1, dtype=torch.int32, device=dev),
+            status=torch.zeros(B, dtype=torch.int32, device=dev),
+            midx=torch.zeros((B, cap), dtype=torch.int32, device=dev),
+            mbest=torch.zeros((B, cap), dtype=torch.int32, device=dev),
+            msecond=torch.zeros((B, cap), dtype=torch.int32, device=dev),
+            done=torch.cuda.Event()))
     gatherer = sharding.RecordGatherer(B, cap, dev) if world > 1 else None
+    state = {"i": 0}
 
     def step():
-        ex.extract_batch_device(d_imgs, B, W, H, W, W * H, d_kps[1:], d_desc[1:], d_counts[1:], d_status, cap)
-        _capi.check(L.orbx_match_bruteforce_device(
-            ex.handle, B, _capi.ptr(d_desc[1:]), _capi.ptr(d_counts[1:]), cap * 32, _capi.ptr(d_desc),
-            _capi.ptr(d_counts), cap * 32, _capi.ptr(d_midx), _capi.ptr(d_mbest), _capi.ptr(d_msecond), cap))
-        if gatherer is not None:
-            gatherer.gather(d_counts[1:], d_kps[1:], d_desc[1:], async_op=True)
-        # carry the last frame into slot 0 for the next step
-        d_desc[0].copy_(d_desc[B]); d_counts[0:1].copy_(d_counts[B:B + 1])
+        i = state["i"]; state["i"] = i + 1
+        k = i % NS
+        e, st, b = exs[k], streams[k], bufs[k]
+        prev = bufs[(i - 1) % NS]
+        with torch.cuda.stream(st):
+            e.extract_batch_device(d_imgs, B, W, H, W, W * H, b["kps"][1:], b["desc"][1:], b["counts"][1:], b["status"], cap)
+            if i > 0:
+                st.wait_event(prev["done"])        # the previous batch's last frame is the train set of pair 0
+            b["desc"][0].copy_(prev["desc"][B]); b["counts"][0:1].copy_(prev["counts"][B:B + 1])
+            _capi.check(L.orbx_match_bruteforce_device(
+                e.handle, B, _capi.ptr(b["desc"][1:]), _capi.ptr(b["counts"][1:]), cap * 32, _capi.ptr(b["desc"]),
+                _capi.ptr(b["counts"]), cap * 32, _capi.ptr(b["midx"]), _capi.ptr(b["mbest"]), _capi.ptr(b["msecond"]), cap))
+            if gatherer is not None:
+                gatherer.gather(b["counts"][1:], b["kps"][1:], b["desc"][1:], async_op=True)
+            b["done"].record(st)
 
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize(dev)
-    status = d_status.cpu().numpy()
+    status = torch.stack([b["status"] for b in bufs]).cpu().numpy()
     if status.any():
         raise SystemExit(f"extraction reported status {status.tolist()}")
-    counts = d_counts[1:].cpu().numpy()
+    counts = bufs[0]["counts"][1:].cpu().numpy()
     n_kp = float(counts.mean())
 
     # calibration pass: which kernel dominates?  (all kernels timed with HIP events on the launch stream)
-    ex.profile_enable(0x1ff)
-    for _ in range(2):
+    for e in exs:
+        e.profile_enable(0x1ff)
+    for _ in range(2 * NS):
         step()
-    prof = ex.profile_read(reset=True)
+    prof = {}
+    for e in exs:
+        for kname, (ms, n) in e.profile_read(reset=True).items():
+            a = prof.get(kname, (0.0, 0))
+            prof[kname] = (a[0] + ms, a[1] + n)
+    prof = {kname: (v[0] / NS, v[1] // NS) for kname, v in prof.items()}   # per 2 steps, like the single-pipeline table
     dominant = max((k for k in prof if k != "misc"), key=lambda k: prof[k][0])
     kid = _capi.K_NAMES.index(dominant)
-    ex.profile_enable(1 << kid)
+    for e in exs:
+        e.profile_enable(1 << kid)
 
     if world > 1:
         dist.barrier()
@@ -156,8 +196,11 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    dom_ms, dom_launches = ex.profile_read(reset=True)[dominant]
-    ex.profile_enable(0)
+    dom_ms, dom_launches = 0.0, 0
+    for e in exs:
+        ms_, n_ = e.profile_read(reset=True)[dominant]
+        dom_ms += ms_; dom_launches += n_
+        e.profile_enable(0)
 
     if rank == 0:
         fps = world * B * args.steps / dt
@@ -173,11 +216,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"synthetic {W}x{H} mono stream, nFeatures={NF}, 8 levels, scale 1.2, FAST 20/7, "
-                                   f"extract+match(t vs t-1), batch {B} frames/GPU resident in HBM",
+                                   f"extract+match(t vs t-1), batch {B} frames/GPU resident in HBM, {NS} pipelines/GPU",
                        "frames_per_gpu_per_step": B, "mean_keypoints": round(n_kp, 1),
                        "parallelism": f"frames sharded x{world}, RCCL all-gather of keypoint records" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": measured_traffic(dominant, B, W, H, NF),
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_us": round(avg_launch_s * 1e6, 2),
                          "end_to_end_GBs": round(total_ab * fps / world / 1e9, 2),

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from orb_slam2_detailed_comments_amd import ORBextractor, synth, _capi
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 frames = synth.stream(640, 480, B, stream_id=100)
 dev = torch.device('cuda', 0)
 d_imgs = torch.from_numpy(frames).to(dev)
