@@ -13,32 +13,56 @@
 // K0: level 0 = reflect-101 border of the input (reference src/ORBextractor.cc:2159-2163)
 // one thread -> 4 horizontally adjacent padded pixels (one dword store)
 // ------------------------------------------------------------------------------------------------
+#define L0_ROWS 8   // rows per thread: 8 independent row loads in flight per lane (the kernel is pure streaming)
 __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restrict__ imgs, int W, int H, int stride,
-                                                long long frame_stride, uint8_t *__restrict__ pyr) {
+                                                long long frame_stride, uint8_t *__restrict__ pyr, int xe) {
+    // block = 64 x 4 threads, thread = L0_ROWS rows.  Blocks with blockIdx.x < gridDim.x - 1 copy the interior
+    // columns [32, xe) with dword-aligned loads + funnel shifts (16 pixels per thread and row); the LAST block column
+    // owns the two border strips [0, 32) and [xe, pitch) where reflect-101 reverses the byte order (byte gathers).
+    // Keeping the two roles in different blocks keeps every wave free of divergence.
     const DLevel &L = g.lv[0];
-    const int X = (blockIdx.x * 64 + threadIdx.x) * 16;   // block = 64 x 4 threads, thread = 16 pixels (one 16-B store)
-    const int Y = blockIdx.y * 4 + threadIdx.y;
+    const int Y0 = (blockIdx.y * 4 + threadIdx.y) * L0_ROWS;
     const int f = blockIdx.z;
-    if (X >= L.pw || Y >= L.ph) return;
-    const uint8_t *src = imgs + (long long)f * frame_stride + (long long)orbx_reflect101(Y - ORBX_EDGE, H) * stride;
-    uint4 v;
-    if (X >= ORBX_EDGE && X + 15 - ORBX_EDGE < W) {
-        __builtin_memcpy(&v, src + (X - ORBX_EDGE), 16);   // interior: one (unaligned) 16-byte load
-    } else {
-        uint32_t w[4];
+    if (Y0 >= L.ph) return;
+    const uint8_t *img = imgs + (long long)f * frame_stride;
+    uint8_t *dst = pyr + (long long)f * g.pyr_bytes + L.off;
+    if (blockIdx.x + 1 < gridDim.x) {
+        const int X = 32 + (blockIdx.x * 64 + threadIdx.x) * 16;
+        if (X >= xe) return;
+        uint4 v[L0_ROWS];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            w[q] = 0;
+        for (int r = 0; r < L0_ROWS; ++r) {
+            const int Y = min(Y0 + r, L.ph - 1);
+            const uint8_t *sp = img + (long long)orbx_reflect101(Y - ORBX_EDGE, H) * stride + (X - ORBX_EDGE);
+            const uint32_t m = (uint32_t)((unsigned long long)sp & 3ull);
+            const uint32_t *ap = (const uint32_t *)(sp - m);
+            const uint32_t q0 = ap[0], q1 = ap[1], q2 = ap[2], q3 = ap[3], q4 = ap[4];
+            v[r] = make_uint4(__builtin_amdgcn_alignbyte(q1, q0, m), __builtin_amdgcn_alignbyte(q2, q1, m),
+                              __builtin_amdgcn_alignbyte(q3, q2, m), __builtin_amdgcn_alignbyte(q4, q3, m));
+        }
+#pragma unroll
+        for (int r = 0; r < L0_ROWS; ++r)
+            if (Y0 + r < L.ph) *(uint4 *)(dst + (long long)(Y0 + r) * L.pitch + X) = v[r];   // pitch % 64 == 0
+    } else {
+        // border strips: dword e < 8 -> X = 4e (left 32 px); e >= 8 -> X = xe + 4(e - 8) (right, up to the pitch)
+        const int e = threadIdx.x;
+        const int X = e < 8 ? 4 * e : xe + 4 * (e - 8);
+        if (X >= L.pitch) return;
+#pragma unroll
+        for (int r = 0; r < L0_ROWS; ++r) {
+            const int Y = Y0 + r;
+            if (Y >= L.ph) break;
+            const uint8_t *src = img + (long long)orbx_reflect101(Y - ORBX_EDGE, H) * stride;
+            uint32_t w = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int x = X + 4 * q + i;
+                const int x = X + i;
                 const uint32_t p = x < L.pw ? src[orbx_reflect101(x - ORBX_EDGE, W)] : 0u;
-                w[q] |= p << (8 * i);
+                w |= p << (8 * i);
             }
+            *(uint32_t *)(dst + (long long)Y * L.pitch + X) = w;
         }
-        v = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    *(uint4 *)(pyr + (long long)f * g.pyr_bytes + L.off + (long long)Y * L.pitch + X) = v;   // pitch % 64 == 0
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -46,22 +70,20 @@ __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restri
 // in one pass: the border is produced by evaluating the bilinear formula at the reflected coordinate
 // (taps precomputed per padded coordinate on the host).  (reference :2119-2143)
 // ------------------------------------------------------------------------------------------------
+#define RS_ROWS 2   // destination rows per thread: the horizontal taps and byte selectors are shared, 12 loads in flight
 __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const OrbxTap *__restrict__ taps,
                                                     uint8_t *__restrict__ pyr) {
-    // block = 64 x 4 threads; thread = 4 horizontally adjacent destination pixels (one dword store).
-    // The <= 8 source pixels a thread needs per source row sit inside 3 aligned dwords: 6 dword loads replace
-    // 16 byte gathers (byte-gather fallback for exotic scale factors whose footprint exceeds 12 bytes).
+    // block = 64 x 4 threads; thread = 4 horizontally adjacent destination pixels x RS_ROWS rows (dword stores).
+    // The <= 8 source pixels a thread needs per source row sit inside 3 aligned dwords: 6 dword loads per
+    // destination row replace 16 byte gathers (byte-gather fallback for exotic scale factors whose footprint
+    // exceeds 12 bytes).
     const DLevel &L = g.lv[level];
     const DLevel &S = g.lv[level - 1];
     const int X = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int Y = blockIdx.y * 4 + threadIdx.y;
+    const int Y0 = (blockIdx.y * 4 + threadIdx.y) * RS_ROWS;
     const int f = blockIdx.z;
-    if (X >= L.pw || Y >= L.ph) return;
+    if (X >= L.pw || Y0 >= L.ph) return;
     uint8_t *base = pyr + (long long)f * g.pyr_bytes;
-    const OrbxTap ty = taps[L.tapy + Y];
-    const uint8_t *r0 = base + S.off + (long long)ty.s0 * S.pitch;
-    const uint8_t *r1 = base + S.off + (long long)ty.s1 * S.pitch;
-    const int b0 = ty.a0, b1 = ty.a1;
     OrbxTap tx[4];
     int smin = 0x7fff, smax = 0;
 #pragma unroll
@@ -71,33 +93,51 @@ __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const Or
         smax = max(smax, (int)tx[i].s0);
     }
     const int xb = smin & ~3;
-    uint32_t v = 0;
-    if (smax + 1 - xb < 12) {
-        const uint32_t *q0 = (const uint32_t *)(r0 + xb), *q1 = (const uint32_t *)(r1 + xb);
-        const uint32_t u0 = q0[0], u1 = q0[1], u2 = q0[2];
-        const uint32_t w0 = q1[0], w1 = q1[1], w2 = q1[2];
+    const bool windowed = smax + 1 - xb < 12;
+    OrbxTap ty[RS_ROWS];
+    uint32_t u[RS_ROWS][3], w[RS_ROWS][3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tx[i].s0 - xb;  // 0..10; the second tap is the next byte (weight 0 whenever clamped)
-            const uint32_t ulo = idx < 4 ? u0 : idx < 8 ? u1 : u2, uhi = idx < 4 ? u1 : idx < 8 ? u2 : 0u;
-            const uint32_t wlo = idx < 4 ? w0 : idx < 8 ? w1 : w2, whi = idx < 4 ? w1 : idx < 8 ? w2 : 0u;
-            const uint32_t pu = __builtin_amdgcn_alignbyte(uhi, ulo, (uint32_t)idx & 3u);
-            const uint32_t pw_ = __builtin_amdgcn_alignbyte(whi, wlo, (uint32_t)idx & 3u);
-            const int T0 = (int)(pu & 0xff) * tx[i].a0 + (int)((pu >> 8) & 0xff) * tx[i].a1;
-            const int T1 = (int)(pw_ & 0xff) * tx[i].a0 + (int)((pw_ >> 8) & 0xff) * tx[i].a1;
-            const uint32_t p = (uint32_t)((((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
-            v |= p << (8 * i);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int T0 = r0[tx[i].s0] * tx[i].a0 + r0[tx[i].s1] * tx[i].a1;
-            const int T1 = r1[tx[i].s0] * tx[i].a0 + r1[tx[i].s1] * tx[i].a1;
-            const uint32_t p = (uint32_t)((((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
-            v |= p << (8 * i);
+    for (int r = 0; r < RS_ROWS; ++r) {
+        ty[r] = taps[L.tapy + min(Y0 + r, L.ph - 1)];
+        if (windowed) {
+            const uint32_t *q0 = (const uint32_t *)(base + S.off + (long long)ty[r].s0 * S.pitch + xb);
+            const uint32_t *q1 = (const uint32_t *)(base + S.off + (long long)ty[r].s1 * S.pitch + xb);
+            u[r][0] = q0[0]; u[r][1] = q0[1]; u[r][2] = q0[2];
+            w[r][0] = q1[0]; w[r][1] = q1[1]; w[r][2] = q1[2];
         }
     }
-    *(uint32_t *)(base + L.off + (long long)Y * L.pitch + X) = v;
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+        const int Y = Y0 + r;
+        if (Y >= L.ph) break;
+        const int b0 = ty[r].a0, b1 = ty[r].a1;
+        uint32_t v = 0;
+        if (windowed) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tx[i].s0 - xb;  // 0..10; the second tap is the next byte (weight 0 whenever clamped)
+                const uint32_t ulo = idx < 4 ? u[r][0] : idx < 8 ? u[r][1] : u[r][2], uhi = idx < 4 ? u[r][1] : idx < 8 ? u[r][2] : 0u;
+                const uint32_t wlo = idx < 4 ? w[r][0] : idx < 8 ? w[r][1] : w[r][2], whi = idx < 4 ? w[r][1] : idx < 8 ? w[r][2] : 0u;
+                const uint32_t pu = __builtin_amdgcn_alignbyte(uhi, ulo, (uint32_t)idx & 3u);
+                const uint32_t pw_ = __builtin_amdgcn_alignbyte(whi, wlo, (uint32_t)idx & 3u);
+                const int T0 = (int)(pu & 0xff) * tx[i].a0 + (int)((pu >> 8) & 0xff) * tx[i].a1;
+                const int T1 = (int)(pw_ & 0xff) * tx[i].a0 + (int)((pw_ >> 8) & 0xff) * tx[i].a1;
+                const uint32_t p = (uint32_t)((((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+                v |= p << (8 * i);
+            }
+        } else {
+            const uint8_t *r0 = base + S.off + (long long)ty[r].s0 * S.pitch;
+            const uint8_t *r1 = base + S.off + (long long)ty[r].s1 * S.pitch;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int T0 = r0[tx[i].s0] * tx[i].a0 + r0[tx[i].s1] * tx[i].a1;
+                const int T1 = r1[tx[i].s0] * tx[i].a0 + r1[tx[i].s1] * tx[i].a1;
+                const uint32_t p = (uint32_t)((((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+                v |= p << (8 * i);
+            }
+        }
+        *(uint32_t *)(base + L.off + (long long)Y * L.pitch + X) = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -830,21 +870,24 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
     uint32_t *patch = s_patch[wv_id];
     uint16_t *hrow = s_h[wv_id];
     const int px0 = x - DS_R, py0 = y - DS_R;
-    const bool interior = px0 >= 0 && py0 >= 0 && px0 + DS_PP <= L.pitch && x + DS_R < L.pw && y + DS_R < L.ph;
+    const int xa = px0 & ~3;
+    const uint32_t shift = (uint32_t)(px0 & 3);
+    const bool interior = px0 >= 0 && py0 >= 0 && xa + 48 <= L.pitch && x + DS_R < L.pw && y + DS_R < L.ph;
     if (interior) {
-        const int dq = lane % 11, rq = lane / 11;     // lanes 0..54 active: 5 rows x 11 dwords per step
-        if (lane < 55) {
-            uint32_t tv[9];
+        // 12 ALIGNED dwords cover the 44 bytes of a patch row; dword d of the LDS row = funnel shift of aligned
+        // dwords d, d+1 (the neighbour lane's register, fetched with one cross-lane read).  5 rows x 12 lanes per step.
+        const int dq = lane % 12, rq = lane / 12;
+        uint32_t tv[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int r = min(5 * k + rq, DS_W - 1);
-                __builtin_memcpy(&tv[k], img + (long long)(py0 + r) * L.pitch + px0 + 4 * dq, 4);
-            }
+        for (int k = 0; k < 9; ++k) {
+            const int r = min(5 * k + rq, DS_W - 1);
+            tv[k] = lane < 60 ? *(const uint32_t *)(img + (long long)(py0 + r) * L.pitch + xa + 4 * dq) : 0u;
+        }
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int r = 5 * k + rq;
-                if (r < DS_W) patch[r * (DS_PP / 4) + dq] = tv[k];
-            }
+        for (int k = 0; k < 9; ++k) {
+            const uint32_t nxt = (uint32_t)__shfl_down((int)tv[k], 1, 64);
+            const int r = 5 * k + rq;
+            if (lane < 60 && dq < 11 && r < DS_W) patch[r * (DS_PP / 4) + dq] = __builtin_amdgcn_alignbyte(nxt, tv[k], shift);
         }
     } else {
         // image edge: reflect-101 of the padded level, byte by byte
@@ -1191,12 +1234,16 @@ void orbx_launch_clear(hipStream_t s, int *a, int na, int *b, int nb, int *c, in
 void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
                         long long frame_stride, uint8_t *pyr) {
     const DLevel &L = g.lv[0];
-    dim3 grid((L.pw + 1023) / 1024, (L.ph + 3) / 4, B);
-    hipLaunchKernelGGL(k_pyr_l0, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr);
+    // interior columns [32, xe): the 20-byte aligned window of every 16-pixel chunk stays inside the source row
+    int xe = 32;
+    while (xe + 1 <= W) xe += 16;           // chunk at X reads source bytes [X - 22, X + 1): must end inside the row
+    const int icols = (xe - 32 + 1023) / 1024;
+    dim3 grid(icols + 1, (L.ph + 4 * L0_ROWS - 1) / (4 * L0_ROWS), B);
+    hipLaunchKernelGGL(k_pyr_l0, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, xe);
 }
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr) {
     const DLevel &L = g.lv[level];
-    dim3 grid((L.pw + 255) / 256, (L.ph + 3) / 4, B);
+    dim3 grid((L.pw + 255) / 256, (L.ph + 4 * RS_ROWS - 1) / (4 * RS_ROWS), B);
     hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, g, level, taps, pyr);
 }
 void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint8_t *pyr, uint2 *cand,
