@@ -179,8 +179,10 @@ __global__ __launch_bounds__(64, 5) void k_fast_cells(DGeom g, const OrbxCell *_
     uint8_t *s_score = fast_smem + rows * FAST_TP;
     uint16_t *s_list = (uint16_t *)(fast_smem + 2 * rows * FAST_TP);          // [0,nA): compass@ini; (lcap-nB, lcap]: compass@min only
     uint16_t *s_corn = (uint16_t *)(fast_smem + 2 * rows * FAST_TP + lcap_b);
+    // blockIdx.x = frame: workgroups are dealt round-robin over the 8 XCDs in linear-id order, so with the frame as
+    // the fastest grid dimension all cell groups of one frame share one XCD's L2 (overlapping tiles are fetched once)
     const int lane = threadIdx.x;
-    const int f = blockIdx.y;
+    const int f = blockIdx.x;
     const int half = lane >> 5, lcol = lane & 31;
     const int rq = lane >> 4, dq = lane & 15;
     const bool two_th = g.min_th != g.ini_th;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(64, 5) void k_fast_cells(DGeom g, const OrbxCell *_
     const int ro[16] = {3 * FAST_TP,      3 * FAST_TP + 1,  2 * FAST_TP + 2,  FAST_TP + 3, 3,  -FAST_TP + 3,
                         -2 * FAST_TP + 2, -3 * FAST_TP + 1, -3 * FAST_TP,     -3 * FAST_TP - 1, -2 * FAST_TP - 2,
                         -FAST_TP - 3,     -3,               FAST_TP - 3,      2 * FAST_TP - 2,  3 * FAST_TP - 1};
-    const int cell0 = cell_begin + blockIdx.x * FAST_CPW;
+    const int cell0 = cell_begin + blockIdx.y * FAST_CPW;
     const int ncell = min(FAST_CPW, cell_end - cell0);
     uint32_t tv[FAST_PF];
     // ---- prefetch of the first tile (all loads in flight before anything waits on them)
@@ -284,8 +286,8 @@ __global__ __launch_bounds__(64, 5) void k_fast_cells(DGeom g, const OrbxCell *_
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int x = ptr[ro[k]];
-                    bright |= (uint32_t)(x > hi) << k;
-                    dark |= (uint32_t)(x < lo) << k;
+                    bright |= x > hi ? (1u << k) : 0u;   // v_cndmask(literal) + v_or: both full rate on gfx950
+                    dark |= x < lo ? (1u << k) : 0u;     // (v_lshl_or_b32 is a half-rate VOP3)
                 }
                 const bool corner = (int)valid & ((int)orbx_arc9(bright) | (int)orbx_arc9(dark));
                 const unsigned long long m = __ballot(corner);
@@ -668,8 +670,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: IC_Angle (reference src/ORBextractor.cc:104-161): one wave per keypoint slot; lanes 0-31 take the
-// row +v, lanes 32-63 the row -v; integer moments reduced across the wave; fastAtan2 on every lane.
+// K4: IC_Angle (reference src/ORBextractor.cc:104-161) is fused into k_describe (K6): the orientation disc lies
+// inside the LDS patch that kernel stages anyway.  Only the slot -> (level, index) helper remains here.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void orbx_slot_to_level(const DGeom &g, int slot, int &level, int &idx) {
     level = 0;
@@ -677,40 +679,6 @@ __device__ __forceinline__ void orbx_slot_to_level(const DGeom &g, int slot, int
     for (int l = 1; l < ORBX_MAX_LEVELS; ++l)
         if (l < g.nlevels && slot >= g.lv[l].kp_begin) level = l;
     idx = slot - g.lv[level].kp_begin;
-}
-
-__global__ __launch_bounds__(256) void k_orient(DGeom g, const uint8_t *__restrict__ pyr,
-                                                const uint32_t *__restrict__ lvl_kp,
-                                                const int *__restrict__ lvl_count, float *__restrict__ lvl_angle) {
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int f = blockIdx.y;
-    if (slot >= g.kp_total) return;
-    int level, idx;
-    orbx_slot_to_level(g, slot, level, idx);
-    const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];       // issued together with the count load
-    const int count = lvl_count[f * g.nlevels + level];
-    if (idx >= count) return;
-    const DLevel &L = g.lv[level];
-    const int x = (int)(pos & 0xfff) + (ORBX_EDGE - 3), y = (int)((pos >> 12) & 0xfff) + (ORBX_EDGE - 3);
-    const uint8_t *center = pyr + (long long)f * g.pyr_bytes + L.off + (long long)y * L.pitch + x;
-    const int u = (lane & 31) - ORBX_HALF_PATCH;  // -15..16
-    const int sgn = lane < 32 ? 1 : -1;
-    // 16 independent byte loads per lane (every address is inside the padded image: |u| <= 16, |v| <= 15 < 19)
-    int vals[ORBX_HALF_PATCH + 1];
-#pragma unroll
-    for (int v = 0; v <= ORBX_HALF_PATCH; ++v) vals[v] = center[u + sgn * v * L.pitch];
-    int m10 = lane < 31 ? u * vals[0] : 0, m01 = 0;
-#pragma unroll
-    for (int v = 1; v <= ORBX_HALF_PATCH; ++v) {
-        const int d = g.umax[v];
-        const int val = (u >= -d && u <= d) ? vals[v] : 0;
-        m10 += u * val;
-        m01 += sgn * v * val;
-    }
-    m10 = orbx_wave_sum(m10);
-    m01 = orbx_wave_sum(m01);
-    if (lane == 0) lvl_angle[(long long)f * g.kp_total + slot] = orbx_fast_atan2((float)m01, (float)m10);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -836,8 +804,8 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
     __shared__ uint32_t s_patch[4][DS_W * DS_PP / 4 + 4];
     __shared__ __attribute__((aligned(8))) uint16_t s_h[4][DS_W * DS_HC];
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 4 + wv_id;
-    const int f = blockIdx.y;
+    const int slot = blockIdx.y * 4 + wv_id;
+    const int f = blockIdx.x;   // frame fastest: one frame's patches stay in one XCD's L2
     if (slot >= g.kp_total) return;
     int level, idx;
     orbx_slot_to_level(g, slot, level, idx);
@@ -1252,7 +1220,7 @@ void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cell
     const int tp = (max_cw + 3 + 3) & ~3;           // +3: dword-alignment shift of the tile origin
     const int lcap = (max_cw - 6) * (max_ch - 6);   // every interior pixel could pass the pre-test
     const size_t smem = (size_t)2 * max_ch * tp + 2 * (size_t)((2 * lcap + 3) & ~3);
-    hipLaunchKernelGGL(k_fast_cells, dim3((cell_end - cell_begin + FAST_CPW - 1) / FAST_CPW, B), dim3(64), smem, s, g, cells,
+    hipLaunchKernelGGL(k_fast_cells, dim3(B, (cell_end - cell_begin + FAST_CPW - 1) / FAST_CPW), dim3(64), smem, s, g, cells,
                        pyr, cand, cell_count, tp, max_ch, lcap, cell_begin, cell_end);
 }
 void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
@@ -1265,17 +1233,13 @@ void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *
 hipError_t orbx_quadtree_prepare(size_t smem) {
     return hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
-void orbx_launch_orient(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
-                        const int *lvl_count, float *lvl_angle) {
-    hipLaunchKernelGGL(k_orient, dim3((g.kp_total + 3) / 4, B), dim3(256), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle);
-}
 void orbx_launch_blur(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, uint8_t *blur) {
     hipLaunchKernelGGL(k_blur, dim3(g.blur_tiles, B), dim3(256), 0, s, g, pyr, blur);
 }
 void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
                           const int *lvl_count, float *lvl_angle, orbx_keypoint *kps, uint8_t *desc,
                           int *counts, int *status, int cap) {
-    hipLaunchKernelGGL(k_describe, dim3((g.kp_total + 3) / 4, B), dim3(256), 0, s, g, pyr, lvl_kp, lvl_count,
+    hipLaunchKernelGGL(k_describe, dim3(B, (g.kp_total + 3) / 4), dim3(256), 0, s, g, pyr, lvl_kp, lvl_count,
                        lvl_angle, kps, desc, counts, status, cap);
 }
 size_t orbx_match_workspace_bytes(int npairs, int out_stride) { return (size_t)npairs * MT_SPLIT * out_stride * sizeof(uint2); }

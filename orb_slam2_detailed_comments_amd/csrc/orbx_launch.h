@@ -15,8 +15,6 @@ void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cell
 void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
                           const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,
                           int *status, uint16_t *knode_glob, int ncap, int lds_keys);
-void orbx_launch_orient(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
-                        const int *lvl_count, float *lvl_angle);
 void orbx_launch_blur(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, uint8_t *blur);
 void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
                           const int *lvl_count, float *lvl_angle, orbx_keypoint *kps, uint8_t *desc,

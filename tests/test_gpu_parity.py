@@ -247,3 +247,42 @@ def test_profile_counters():
     assert p["k_blur"][1] == 0                      # the Gaussian is fused into k_describe
     ex.pyramid_level(0, 0, blur=True)               # ... and only materialised on request
     assert ex.profile_read()["k_blur"][1] == 1
+
+
+def test_two_handles_from_two_threads():
+    """stereo pattern of the reference (src/Frame.cc:158-168): two extractor instances driven concurrently by two
+    std::threads; distinct handles own distinct streams and workspaces"""
+    import threading
+    L, R = synth.stereo_pair(640, 480, stream_id=9)
+    exL, exR = ORBextractor(1000), ORBextractor(1000)
+    out = {}
+
+    def work(name, ex, img):
+        for _ in range(5):
+            out[name] = ex(img)
+
+    th = [threading.Thread(target=work, args=("L", exL, L)), threading.Thread(target=work, args=("R", exR, R))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    orc = oracle.OracleExtractor(1000)
+    assert_frame_equal(out["L"], orc.extract(L), "left")
+    assert_frame_equal(out["R"], orc.extract(R), "right")
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE json line with the contract keys (tiny run)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    j = json.loads(line[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "u8" and j["value"] > 1000
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
