@@ -178,6 +178,24 @@ orbx_status orbx_search_by_projection_frame(orbx_handle *h, const orbx_frame_vie
                                             float th, int mono, int check_orientation, int32_t *matched_last,
                                             int *nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (src/ORBmatcher.cc:69-184; caller
+ * Tracking::SearchLocalPoints, src/Tracking.cc:1953).  MapPoint fields (written by Frame::isInFrustum in the reference)
+ * as arrays; frame_observations[idx] = Observations() of the MapPoint already attached to feature idx, -1 if none.
+ * assigned[idx] = index of the MapPoint newly attached to feature idx, or -1.  Only frame->keys_un/desc/u_right/n and
+ * the bounds of `frame` are read. */
+typedef struct orbx_mappoint_view {
+    int32_t n;
+    const uint8_t *in_view;       /* mbTrackInView && !isBad() */
+    const float *proj;            /* mTrackProjX, mTrackProjY, mTrackProjXR: 3 floats per point */
+    const int32_t *level;         /* mnTrackScaleLevel */
+    const float *view_cos;        /* mTrackViewCos */
+    const uint8_t *desc;          /* GetDescriptor(), 32 bytes per point */
+    const int32_t *observations;  /* Observations() */
+} orbx_mappoint_view;
+orbx_status orbx_search_by_projection_mappoints(orbx_handle *h, const orbx_frame_view *frame,
+                                                const int32_t *frame_observations, const orbx_mappoint_view *mps,
+                                                float th, float nnratio, int32_t *assigned, int *nmatches);
+
 /* ---- stream / timing plumbing ------------------------------------------------------------ */
 void *orbx_get_stream(orbx_handle *h);            /* hipStream_t */
 orbx_status orbx_set_stream(orbx_handle *h, void *hip_stream); /* NULL restores the private stream */

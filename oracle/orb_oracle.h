@@ -113,6 +113,12 @@ int orc_search_by_projection_ff(const orc_keypoint *kc, const uint8_t *dc, const
                                 const orc_keypoint *kl, int nl, const uint8_t *has_mp, const float *xw,
                                 const uint8_t *mpdesc, const int *obs, const float *Tlw, float th, int bMono,
                                 int check_ori, int fp_mode, int *matched_last);
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (local-map tracking); assigned[nf] out */
+int orc_search_by_projection_mp(const orc_keypoint *kf, const uint8_t *df, const float *u_right, const int *frame_obs,
+                                int nf, float minx, float maxx, float miny, float maxy, const float *scale_factors,
+                                int nmp, const uint8_t *in_view, const float *proj, const int *level,
+                                const float *view_cos, const uint8_t *mpdesc, const int *mp_obs, float th, float nnratio,
+                                int *assigned);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,9 @@ def lib():
         L.orc_search_by_projection_ff.argtypes = ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_float] * 10 +
                                                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p])
+        L.orc_search_by_projection_mp.restype = C.c_int
+        L.orc_search_by_projection_mp.argtypes = ([C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_int] +
+                                                  [C.c_void_p] * 6 + [C.c_float, C.c_float, C.c_void_p])
         _LIB = L
     return _LIB
 
@@ -255,3 +258,17 @@ def search_by_projection_ff(kc, dc, u_right, Tcw, K, bounds, mb, mbf, scale, kl,
                                           *[float(b) for b in bounds], mb, mbf, _p(scale), _p(kl), len(kl), _p(has_mp),
                                           _p(xw), _p(mpdesc), _p(obs), _p(Tlw), th, int(mono), int(check_ori), fp_mode, _p(out))
     return n, out[:len(kc)].copy()
+
+
+def search_by_projection_mp(kf, df, u_right, frame_obs, bounds, scale, in_view, proj, level, view_cos, mpdesc, mp_obs, th,
+                            nnratio):
+    kf = np.ascontiguousarray(kf, KP_DTYPE)
+    a = lambda x, t: np.ascontiguousarray(x, t)
+    df, mpdesc, in_view = a(df, np.uint8), a(mpdesc, np.uint8), a(in_view, np.uint8)
+    u_right, proj, view_cos, scale = (a(x, np.float32) for x in (u_right, proj, view_cos, scale))
+    frame_obs, level, mp_obs = (a(x, np.int32) for x in (frame_obs, level, mp_obs))
+    out = np.full(max(len(kf), 1), -1, np.int32)
+    n = lib().orc_search_by_projection_mp(_p(kf), _p(df), _p(u_right), _p(frame_obs), len(kf), *[float(b) for b in bounds],
+                                          _p(scale), len(in_view), _p(in_view), _p(proj), _p(level), _p(view_cos), _p(mpdesc),
+                                          _p(mp_obs), th, nnratio, _p(out))
+    return n, out[:len(kf)].copy()

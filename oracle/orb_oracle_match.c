@@ -380,3 +380,56 @@ int orc_search_by_projection_ff(const orc_keypoint *kc, const uint8_t *dc, const
     free(hist); free(cands);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------ SearchByProjection(Frame&, vector<MapPoint*>&, th) */
+/* src/ORBmatcher.cc:69-184 (+ RadiusByViewingCos :187-194); caller Tracking::SearchLocalPoints src/Tracking.cc:1953.
+ * MapPoint fields as arrays (filled by Frame::isInFrustum in the reference): in_view[i] = mbTrackInView && !isBad(),
+ * proj[3*i] = (mTrackProjX, mTrackProjY, mTrackProjXR), level[i] = mnTrackScaleLevel, view_cos[i] = mTrackViewCos,
+ * mpdesc = GetDescriptor(), mp_obs[i] = Observations().  Frame: keypoints, descriptors, u_right, and frame_obs[idx] =
+ * Observations() of the MapPoint already attached to feature idx (-1: none).  Output assigned[idx] = index of the
+ * MapPoint newly attached to feature idx, or -1. */
+int orc_search_by_projection_mp(const orc_keypoint *kf, const uint8_t *df, const float *u_right, const int *frame_obs,
+                                int nf, float minx, float maxx, float miny, float maxy, const float *scale_factors,
+                                int nmp, const uint8_t *in_view, const float *proj, const int *level,
+                                const float *view_cos, const uint8_t *mpdesc, const int *mp_obs, float th, float nnratio,
+                                int *assigned) {
+    int nmatches = 0;
+    int *occ = (int *)malloc(sizeof(int) * (nf > 0 ? nf : 1)); /* Observations() of whatever sits at feature idx now */
+    for (int i = 0; i < nf; ++i) { assigned[i] = -1; occ[i] = frame_obs[i]; }
+    const int bFactor = th != 1.0;
+    orc_grid *g = orc_grid_build(kf, nf, minx, maxx, miny, maxy);
+    int *cands = (int *)malloc(sizeof(int) * (nf > 0 ? nf : 1));
+    for (int iMP = 0; iMP < nmp; iMP++) {
+        if (!in_view[iMP]) continue;
+        const int nPredictedLevel = level[iMP];
+        float r = view_cos[iMP] > 0.998 ? 2.5f : 4.0f;
+        if (bFactor) r *= th;
+        const int nc = orc_grid_query(g, proj[3 * iMP], proj[3 * iMP + 1], r * scale_factors[nPredictedLevel],
+                                      nPredictedLevel - 1, nPredictedLevel, cands, nf);
+        if (nc == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int idx = cands[c];
+            if (occ[idx] > 0) continue; /* F.mvpMapPoints[idx] && Observations() > 0 */
+            if (u_right[idx] > 0) {
+                const float er = fabsf(proj[3 * iMP + 2] - u_right[idx]);
+                if (er > r * scale_factors[nPredictedLevel]) continue;
+            }
+            const int dist = orc_descriptor_distance(mpdesc + (size_t)iMP * 32, df + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kf[idx].octave; bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = kf[idx].octave; bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            assigned[bestIdx] = iMP;
+            occ[bestIdx] = mp_obs[iMP];
+            nmatches++;
+        }
+    }
+    orc_grid_free(g);
+    free(occ); free(cands);
+    return nmatches;
+}

@@ -38,6 +38,11 @@ class LastFrameView(C.Structure):
                 ("mp_desc", C.c_void_p), ("observations", C.c_void_p), ("Tcw", C.c_float * 16)]
 
 
+class MapPointView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("in_view", C.c_void_p), ("proj", C.c_void_p), ("level", C.c_void_p),
+                ("view_cos", C.c_void_p), ("desc", C.c_void_p), ("observations", C.c_void_p)]
+
+
 class OrbxError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"orbx status {status}: {msg}")
@@ -55,6 +60,7 @@ SYMBOLS = [
     "orbx_kernel_name", "orbx_debug_candidates", "orbx_debug_level_keypoints", "orbx_debug_blur_copy",
     "orbx_grid_create", "orbx_grid_destroy", "orbx_grid_query", "orbx_three_maxima",
     "orbx_search_for_initialization", "orbx_stereo_match", "orbx_search_by_projection_frame",
+    "orbx_search_by_projection_mappoints",
 ]
 
 _lib = None
@@ -116,6 +122,9 @@ def lib():
     L.orbx_search_by_projection_frame.restype = i32
     L.orbx_search_by_projection_frame.argtypes = [vp, C.POINTER(FrameView), C.POINTER(LastFrameView), f32, i32, i32, vp,
                                                   C.POINTER(i32)]
+    L.orbx_search_by_projection_mappoints.restype = i32
+    L.orbx_search_by_projection_mappoints.argtypes = [vp, C.POINTER(FrameView), vp, C.POINTER(MapPointView), f32, f32, vp,
+                                                      C.POINTER(i32)]
     _lib = L
     return L
 

@@ -952,3 +952,66 @@ extern "C" orbx_status orbx_search_by_projection_frame(orbx_handle *h, const orb
     *nmatches_out = nmatches;
     return ORBX_OK;
 }
+
+// ---------------------------------------------------------------- (f)1: SearchByProjection(Frame&, vector<MapPoint*>&, th)
+// (src/ORBmatcher.cc:69-184, RadiusByViewingCos :187-194; caller Tracking::SearchLocalPoints src/Tracking.cc:1953) --
+// the largest per-frame matcher load in steady state.  GPU: Hamming matrix between the descriptors of the MapPoints
+// in view and the frame's descriptors.  Host: grid gating, occupancy rule, level-aware ratio test (order-dependent).
+extern "C" orbx_status orbx_search_by_projection_mappoints(orbx_handle *h, const orbx_frame_view *frame,
+                                                           const int32_t *frame_observations,
+                                                           const orbx_mappoint_view *mps, float th, float nnratio,
+                                                           int32_t *assigned, int *nmatches_out) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (!frame || !mps || !assigned || !nmatches_out || frame->n < 0 || mps->n < 0) return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    const int nf = frame->n, nmp = mps->n, TH_HIGH_ = 100;
+    *nmatches_out = 0;
+    for (int i = 0; i < nf; ++i) assigned[i] = -1;
+    if (nf == 0 || nmp == 0) return ORBX_OK;
+    if (!frame->keys_un || !frame->desc || !frame->u_right || !frame_observations || !mps->in_view || !mps->proj ||
+        !mps->level || !mps->view_cos || !mps->desc || !mps->observations)
+        return fail(ORBX_BAD_ARGUMENT, "null field");
+    std::vector<int> rows, rpos(nmp, -1);
+    for (int i = 0; i < nmp; ++i) if (mps->in_view[i]) { rpos[i] = (int)rows.size(); rows.push_back(i); }
+    if (rows.empty()) return ORBX_OK;
+    std::vector<uint8_t> q(rows.size() * 32);
+    for (size_t r = 0; r < rows.size(); ++r) memcpy(&q[r * 32], mps->desc + (size_t)rows[r] * 32, 32);
+    std::vector<uint16_t> D(rows.size() * (size_t)nf);
+    orbx_status st = orbx_hamming_matrix(h, q.data(), (int)rows.size(), frame->desc, nf, D.data());
+    if (st != ORBX_OK) return st;
+    orbx_grid *grid = orbx_grid_create(frame->keys_un, nf, frame->min_x, frame->max_x, frame->min_y, frame->max_y);
+    if (!grid) return fail(ORBX_BAD_ARGUMENT, "bad image bounds");
+    std::vector<int> occ(frame_observations, frame_observations + nf), cands(nf);
+    const bool bFactor = th != 1.0;
+    int nmatches = 0;
+    for (int iMP = 0; iMP < nmp; ++iMP) {
+        if (!mps->in_view[iMP]) continue;
+        const int lvl = mps->level[iMP];
+        if (lvl < 0 || lvl >= h->p.nlevels) continue;
+        float r = mps->view_cos[iMP] > 0.998 ? 2.5f : 4.0f;
+        if (bFactor) r *= th;
+        const float radius = r * h->tab.scale[lvl];
+        const int nc = orbx_grid_query(grid, mps->proj[3 * iMP], mps->proj[3 * iMP + 1], radius, lvl - 1, lvl, cands.data(), nf);
+        if (nc == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int idx = cands[c];
+            if (occ[idx] > 0) continue;
+            if (frame->u_right[idx] > 0 && fabsf(mps->proj[3 * iMP + 2] - frame->u_right[idx]) > radius) continue;
+            const int dist = (int)D[(size_t)rpos[iMP] * nf + idx];
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = frame->keys_un[idx].octave; bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = frame->keys_un[idx].octave; bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH_) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+            assigned[bestIdx] = iMP;
+            occ[bestIdx] = mps->observations[iMP];
+            nmatches++;
+        }
+    }
+    orbx_grid_destroy(grid);
+    *nmatches_out = nmatches;
+    return ORBX_OK;
+}

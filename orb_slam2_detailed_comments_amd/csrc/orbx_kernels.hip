@@ -169,9 +169,13 @@ __device__ __forceinline__ void orbx_wave_sync() {
 #define FAST_CPW 4      // cells per wave: prologue amortised, next tile prefetched into registers during compute
 #define FAST_PF 10      // prefetch registers: 4 rows x 16 dwords per step -> cells up to 40 rows x 61 px (all but tiny levels)
 
+// FAST_TP (LDS tile pitch) is a template constant: row offsets become shifts/immediates instead of the quarter-rate
+// v_mul_lo_u32, and the 16 ring offsets fold into the ds_read offset field.  44 covers cells up to 38 px wide
+// (every level of the usual geometries), 72 the widest cells of tiny pyramid levels.
+template <int FAST_TP>
 __global__ __launch_bounds__(64, 5) void k_fast_cells(DGeom g, const OrbxCell *__restrict__ cells,
                                                    const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
-                                                   int *__restrict__ cell_count, int FAST_TP, int rows, int lcap,
+                                                   int *__restrict__ cell_count, int rows, int lcap,
                                                    int cell_begin, int cell_end) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
     const int lcap_b = (2 * lcap + 3) & ~3;
@@ -1217,11 +1221,17 @@ void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, con
 void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint8_t *pyr, uint2 *cand,
                       int *cell_count, int max_cw, int max_ch, int cell_begin, int cell_end) {
     if (cell_end <= cell_begin) return;
-    const int tp = (max_cw + 3 + 3) & ~3;           // +3: dword-alignment shift of the tile origin
+    const int need = (max_cw + 3 + 3) & ~3;         // +3: dword-alignment shift of the tile origin
+    const int tp = need <= 44 ? 44 : 72;            // template instances of the tile pitch (host geometry caps cw at 67)
     const int lcap = (max_cw - 6) * (max_ch - 6);   // every interior pixel could pass the pre-test
     const size_t smem = (size_t)2 * max_ch * tp + 2 * (size_t)((2 * lcap + 3) & ~3);
-    hipLaunchKernelGGL(k_fast_cells, dim3(B, (cell_end - cell_begin + FAST_CPW - 1) / FAST_CPW), dim3(64), smem, s, g, cells,
-                       pyr, cand, cell_count, tp, max_ch, lcap, cell_begin, cell_end);
+    const dim3 grid(B, (cell_end - cell_begin + FAST_CPW - 1) / FAST_CPW);
+    if (tp == 44)
+        hipLaunchKernelGGL(k_fast_cells<44>, grid, dim3(64), smem, s, g, cells, pyr, cand, cell_count, max_ch, lcap, cell_begin,
+                           cell_end);
+    else
+        hipLaunchKernelGGL(k_fast_cells<72>, grid, dim3(64), smem, s, g, cells, pyr, cand, cell_count, max_ch, lcap, cell_begin,
+                           cell_end);
 }
 void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
                           const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,

@@ -86,6 +86,25 @@ class ORBmatcher:
                                                       int(self.mbCheckOrientation), ptr(out), C.byref(n)))
         return n.value, out[:cur.N].copy()
 
+    # ---- SearchByProjection(F, vpMapPoints, th) (src/ORBmatcher.cc:69-184): local-map tracking
+    def SearchByProjectionMapPoints(self, F, th, *, frame_observations, in_view, proj, level, view_cos, mp_desc,
+                                    observations):
+        """F: frame.Frame; MapPoint fields as arrays.  Returns (nmatches, assigned[F.N])."""
+        import ctypes as C
+        keep = [np.ascontiguousarray(a, t) for a, t in ((F.mvuRight, np.float32), (frame_observations, np.int32),
+                                                         (in_view, np.uint8), (proj, np.float32), (level, np.int32),
+                                                         (view_cos, np.float32), (mp_desc, np.uint8), (observations, np.int32))]
+        fv, mv = _capi.FrameView(), _capi.MapPointView()
+        fv.keys_un, fv.desc, fv.u_right, fv.n = F.mvKeysUn.ctypes.data, F.mDescriptors.ctypes.data, keep[0].ctypes.data, F.N
+        fv.min_x, fv.max_x, fv.min_y, fv.max_y = F.bounds
+        mv.n = len(keep[2])
+        mv.in_view, mv.proj, mv.level, mv.view_cos, mv.desc, mv.observations = (k.ctypes.data for k in keep[2:])
+        out = np.full(max(F.N, 1), -1, np.int32)
+        n = C.c_int(0)
+        check(self._L.orbx_search_by_projection_mappoints(self._ex.handle, C.byref(fv), ptr(keep[1]), C.byref(mv), float(th),
+                                                          float(self.mfNNratio), ptr(out), C.byref(n)))
+        return n.value, out[:F.N].copy()
+
     # ---- ComputeThreeMaxima (src/ORBmatcher.cc:2026-2068): 30 numbers, host side
     @staticmethod
     def ComputeThreeMaxima(sizes):

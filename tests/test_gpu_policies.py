@@ -107,3 +107,31 @@ def test_search_by_projection_frame_to_frame(mono, th, motion):
     assert n == on and np.array_equal(matched, omatched)
     if motion == "side":
         assert n > 100
+
+
+@pytest.mark.parametrize("th,ratio,stereo", [(1.0, 0.8, False), (3.0, 0.8, True), (5.0, 0.6, False)])
+def test_search_by_projection_local_map_points(th, ratio, stereo):
+    """Tracking::SearchLocalPoints' matcher (src/Tracking.cc:1938-1953): map points = last frame's features projected
+    where the translated scene puts them, plus distractors; some frame features already carry observed points."""
+    frames = synth.stream(640, 480, 2, stream_id=6)
+    ex = ORBextractor(1000, max_batch=2)
+    (k0, d0), (k1, d1) = ex.extract_batch(frames)
+    F = Frame(k1, d1, 640, 480)
+    rng = np.random.default_rng(3)
+    nmp = len(k0)
+    proj = np.stack([k0["x"] + 3.0 + rng.normal(0, 1.0, nmp), k0["y"] + 2.0 + rng.normal(0, 1.0, nmp),
+                     k0["x"] + 3.0 - 20.0], 1).astype(np.float32)
+    in_view = (rng.uniform(size=nmp) < 0.85).astype(np.uint8)
+    level = np.clip(k0["octave"] + rng.integers(-1, 2, nmp), 0, 7).astype(np.int32)
+    view_cos = rng.uniform(0.99, 1.0, nmp).astype(np.float32)
+    mp_obs = rng.integers(0, 4, nmp).astype(np.int32)
+    frame_obs = np.where(rng.uniform(size=F.N) < 0.2, rng.integers(0, 3, F.N), -1).astype(np.int32)
+    if stereo:
+        F.mvuRight[::2] = (k1["x"][::2] - 20.0 + rng.normal(0, 2.0, len(k1[::2]))).astype(np.float32)
+    m = ORBmatcher(ratio, True, extractor=ex)
+    n, assigned = m.SearchByProjectionMapPoints(F, th, frame_observations=frame_obs, in_view=in_view, proj=proj, level=level,
+                                                view_cos=view_cos, mp_desc=d0, observations=mp_obs)
+    on, oassigned = oracle.search_by_projection_mp(k1, d1, F.mvuRight, frame_obs, (0, 640, 0, 480), ex.GetScaleFactors(),
+                                                   in_view, proj, level, view_cos, d0, mp_obs, th, ratio)
+    assert n == on and np.array_equal(assigned, oassigned)
+    assert n > 30
