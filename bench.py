@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="independent extract+match pipelines per GPU, used round-robin (3 adds ~10 %% throughput but "
                          "overlapping kernels blur the per-kernel timing; default 1 keeps the roofline accounting clean)")
+    ap.add_argument("--gather", default="gather", choices=("gather", "all_gather"),
+                    help="collective for the per-frame keypoint records: to rank 0 (default) or to every rank")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also print a per-kernel table to stderr")
     args = ap.parse_args()
@@ -104,11 +107,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ORB front-end has no CPU fallback")
+    if os.environ.get("ORBX_BENCH_SHARE_GPU0"):   # rehearsal of the N > 1 code path on a one-GPU box (gloo backend)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     B, W, H, NF = args.batch, args.width, args.height, args.nfeatures
     NS = max(1, args.streams)
@@ -135,7 +143,7 @@ def main():
             mbest=torch.zeros((B, cap), dtype=torch.int32, device=dev),
             msecond=torch.zeros((B, cap), dtype=torch.int32, device=dev),
             done=torch.cuda.Event()))
-    gatherer = sharding.RecordGatherer(B, cap, dev) if world > 1 else None
+    gatherer = sharding.RecordGatherer(B, cap, dev, mode=args.gather) if world > 1 else None
     state = {"i": 0}
 
     def step():
@@ -218,7 +226,7 @@ def main():
             "config": {"workload": f"synthetic {W}x{H} mono stream, nFeatures={NF}, 8 levels, scale 1.2, FAST 20/7, "
                                    f"extract+match(t vs t-1), batch {B} frames/GPU resident in HBM, {NS} pipelines/GPU",
                        "frames_per_gpu_per_step": B, "mean_keypoints": round(n_kp, 1),
-                       "parallelism": f"frames sharded x{world}, RCCL all-gather of keypoint records" if world > 1 else "single GPU"},
+                       "parallelism": f"frames sharded x{world}, RCCL {args.gather} of keypoint records per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": measured_traffic(dominant, B, W, H, NF),

@@ -52,15 +52,21 @@ class RecordGatherer:
     """One all-gather of equal-sized per-rank record blocks per batch, optionally left in flight
     (async) while the next batch is computed."""
 
-    def __init__(self, frames_per_rank: int, cap: int, device, group=None):
+    def __init__(self, frames_per_rank: int, cap: int, device, group=None, mode: str = "gather", root: int = 0):
+        """mode "gather": records go to rank `root` only (the consumer of the keypoints; 1/N of the all-gather traffic);
+        mode "all_gather": every rank receives every record."""
+        assert mode in ("gather", "all_gather")
+        self.mode, self.root = mode, root
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
         self.cap = cap
         self.rb = record_bytes(cap)
         self.frames_per_rank = frames_per_rank
         self.send = [torch.empty((frames_per_rank, self.rb), dtype=torch.uint8, device=device) for _ in range(2)]
-        self.recv = [torch.empty((self.world * frames_per_rank, self.rb), dtype=torch.uint8, device=device)
-                     for _ in range(2)]
+        need_recv = mode == "all_gather" or self.rank == root
+        self.recv = [torch.empty((self.world * frames_per_rank, self.rb) if need_recv else (0, self.rb),
+                                 dtype=torch.uint8, device=device) for _ in range(2)]
         self.work = [None, None]
         self.slot = 0
 
@@ -73,8 +79,11 @@ class RecordGatherer:
         if self.world == 1:
             self.recv[s].copy_(self.send[s])
             w = None
-        else:
+        elif self.mode == "all_gather":
             w = dist.all_gather_into_tensor(self.recv[s], self.send[s], group=self.group, async_op=async_op)
+        else:
+            parts = list(self.recv[s].view(self.world, self.frames_per_rank, self.rb).unbind(0)) if self.rank == self.root else None
+            w = dist.gather(self.send[s], parts, dst=self.root, group=self.group, async_op=async_op)
         self.work[s] = w if async_op else None
         self.slot ^= 1
         return self.recv[s]

@@ -32,17 +32,21 @@ def _worker(rank, world, port, frames, cap, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = sharding.RecordGatherer(frames, cap, torch.device("cpu"))
         ok = True
-        for it, async_op in enumerate((False, True, True)):
-            counts, kps, desc = _fake_records(rank + 10 * it, frames, cap)
-            buf = g.gather(counts, kps, desc, async_op=async_op)
-            g.wait_all()
-            c, k, d = sharding.unpack_records(buf, cap)
-            for r in range(world):
-                ec, ek, ed = _fake_records(r + 10 * it, frames, cap)
-                sl = slice(r * frames, (r + 1) * frames)
-                ok &= bool(torch.equal(c[sl], ec) and torch.equal(k[sl], ek) and torch.equal(d[sl], ed))
+        for mode in ("all_gather", "gather"):
+            g = sharding.RecordGatherer(frames, cap, torch.device("cpu"), mode=mode)
+            for it, async_op in enumerate((False, True, True)):
+                counts, kps, desc = _fake_records(rank + 10 * it, frames, cap)
+                buf = g.gather(counts, kps, desc, async_op=async_op)
+                g.wait_all()
+                if mode == "gather" and rank != 0:
+                    ok &= buf.shape[0] == 0             # only the root receives
+                    continue
+                c, k, d = sharding.unpack_records(buf, cap)
+                for r in range(world):
+                    ec, ek, ed = _fake_records(r + 10 * it, frames, cap)
+                    sl = slice(r * frames, (r + 1) * frames)
+                    ok &= bool(torch.equal(c[sl], ec) and torch.equal(k[sl], ek) and torch.equal(d[sl], ed))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
