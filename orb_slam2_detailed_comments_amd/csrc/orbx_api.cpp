@@ -172,11 +172,11 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     d.blur_tiles = tiles;
     // quadtree LDS plan: node tables always in LDS, key->node map in LDS when the level's candidates fit
     h->ncap = g.node_cap;
-    // keys of a level live in LDS when they fit 12288 slots (24 KB): keeps >= 2 quadtree workgroups per CU;
+    // keys of a level (position + node index) live in LDS when they fit 4096 slots (24 KB): keeps >= 2 workgroups per CU;
     // denser levels fall back to the global scratch map (same code path through a generic pointer)
     const size_t node_part = orbx_quadtree_smem(h->ncap, 0);
     if (node_part > 120 * 1024) return fail(ORBX_UNSUPPORTED, "nfeatures too large for the LDS quadtree node table");
-    h->lds_keys = (int)std::min<size_t>(12288, (size_t)g.max_cand_cap);
+    h->lds_keys = (int)std::min<size_t>(4096, (size_t)g.max_cand_cap);   // 6 bytes per key: position + node
     HIPCHK(orbx_quadtree_prepare(orbx_quadtree_smem(h->ncap, h->lds_keys)));
     // buffers
     HIPCHK(hipMalloc(&h->d_pyr, (size_t)B * g.pyr_bytes + 256));   // +256: kernels read whole aligned dwords

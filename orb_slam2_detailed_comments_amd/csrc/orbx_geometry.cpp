@@ -161,7 +161,7 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
         L.cand_cap = std::max(64, nms_bound);
         L.cand_begin = cand_off;
         cand_off += L.cand_cap;
-        g.node_cap = std::max(g.node_cap, L.kp_cap + 8);
+        g.node_cap = std::max(g.node_cap, (L.kp_cap + 8 + 3) & ~3);   // multiple of 4: LDS arrays stay 16-byte aligned
         g.max_cand_cap = std::max(g.max_cand_cap, L.cand_cap);
         // resize taps (level > 0: source is the PADDED previous level)
         L.tapx_begin = L.tapy_begin = 0;

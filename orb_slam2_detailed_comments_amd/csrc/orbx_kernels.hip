@@ -389,11 +389,11 @@ struct QtShared {
     uint32_t carry;
 };
 
-// exclusive prefix sum of in[0..n) -> out[0..n) (both LDS), returns total; all threads must call
+// exclusive prefix sum of in[0..n) -> out[0..n) (both LDS, may alias), returns total; all threads must call.
+// Two barriers per 512-element chunk: wave scan -> wave totals in LDS -> every thread adds the totals before it.
 __device__ uint32_t qt_block_scan(const uint32_t *in, uint32_t *out, int n, QtShared *sh) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) sh->carry = 0;
-    __syncthreads();
+    uint32_t carry = 0;
     for (int base = 0; base < n; base += QT_THREADS) {
         const int i = base + tid;
         const uint32_t v = i < n ? in[i] : 0;
@@ -405,18 +405,18 @@ __device__ uint32_t qt_block_scan(const uint32_t *in, uint32_t *out, int n, QtSh
         }
         if (lane == 63) sh->wsum[w] = incl;
         __syncthreads();
-        uint32_t off = sh->carry;
-        for (int j = 0; j < w; ++j) off += sh->wsum[j];
-        if (i < n) out[i] = off + incl - v;
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t t = 0;
-            for (int j = 0; j < QT_THREADS / 64; ++j) t += sh->wsum[j];
-            sh->carry += t;
+        uint32_t off = carry, tot = 0;
+#pragma unroll
+        for (int j = 0; j < QT_THREADS / 64; ++j) {
+            const uint32_t t = sh->wsum[j];
+            off += j < w ? t : 0u;
+            tot += t;
         }
-        __syncthreads();
+        if (i < n) out[i] = off + incl - v;
+        carry += tot;
+        __syncthreads();   // results visible to every thread; wsum free for the next chunk / call
     }
-    return sh->carry;
+    return carry;
 }
 
 __device__ __forceinline__ int qt_quadrant(uint32_t pos, uint32_t b0, uint32_t b1) {
@@ -469,6 +469,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
     uint32_t *t3 = (uint32_t *)sp;                 sp += 4 * (size_t)ncap;   // careful: rank / by-rank data
     uint32_t *t4 = (uint32_t *)sp;                 sp += 4 * (size_t)ncap;
     uint32_t *t5 = (uint32_t *)sp;                 sp += 4 * (size_t)ncap;
+    uint32_t *kpos_lds = (uint32_t *)sp;           sp += 4 * (size_t)lds_keys;  // key positions (x:12 y:12 score:8) when K <= lds_keys
     uint16_t *knode_lds = (uint16_t *)sp;
     uint32_t *box0 = boxA0, *box1 = boxA1, *cnt = cntA, *meta = metaA;
     uint32_t *nbox0 = boxB0, *nbox1 = boxB1, *ncnt = cntB, *nmeta = metaB;
@@ -490,17 +491,27 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
     }
     __syncthreads();
     const int K = (int)qt_block_scan(cscan, cscan, QT_THREADS, sh);
+    const bool keys_in_lds = K <= lds_keys;   // wave-uniform: key positions and key->node map live in LDS
     {
         uint32_t o = cscan[tid];
         for (int i = c_begin; i < c_end; ++i) {
             const OrbxCell cl = cells[L.cell_begin + i];
             const int c = min(cell_count[(long long)f * g.ncells + L.cell_begin + i], cl.slot_cap);
-            for (int e = 0; e < c; ++e) cand[o + e] = slots[cl.slot_begin + e];
+            const uint2 *src = slots + cl.slot_begin;
+            // the first four entries are fetched together (slot ranges are always mapped): one memory round trip
+            // covers the typical cell, which holds 0..4 survivors
+            const uint2 e0 = src[0], e1 = src[min(1, cl.slot_cap - 1)], e2 = src[min(2, cl.slot_cap - 1)], e3 = src[min(3, cl.slot_cap - 1)];
+            for (int e = 0; e < c; ++e) {
+                const uint2 v = e == 0 ? e0 : e == 1 ? e1 : e == 2 ? e2 : e == 3 ? e3 : src[e];
+                cand[o + e] = v;
+                if (keys_in_lds) kpos_lds[o + e] = v.x;
+            }
             o += (uint32_t)c;
         }
     }
     if (tid == 0) cand_count[f * g.nlevels + level] = K;
-    uint16_t *knode = (K <= lds_keys) ? knode_lds : knode_glob + ((long long)f * g.cand_total + L.cand_begin);
+    uint16_t *knode = keys_in_lds ? knode_lds : knode_glob + ((long long)f * g.cand_total + L.cand_begin);
+#define QT_KPOS(k) (keys_in_lds ? kpos_lds[k] : cand[k].x)
     __syncthreads();
     // ---- roots (:1060-1135)
     const int nini = L.nini;
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
     for (int i = tid; i < nini; i += QT_THREADS) cc[i] = 0;
     __syncthreads();
     for (int k = tid; k < K; k += QT_THREADS) {
-        const int x = cand[k].x & 0xfff;
+        const int x = QT_KPOS(k) & 0xfff;
         int b = (int)((float)x / hx);
         b = min(b, nini - 1);
         knode[k] = (uint16_t)b;
@@ -548,7 +559,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
         // ---- B: quadrant census
         for (int k = tid; k < K; k += QT_THREADS) {
             const int p = knode[k];
-            if ((meta[p] >> 16) & 1) atomicAdd(&cc[4 * p + qt_quadrant(cand[k].x, box0[p], box1[p])], 1u);
+            if ((meta[p] >> 16) & 1) atomicAdd(&cc[4 * p + qt_quadrant(QT_KPOS(k), box0[p], box1[p])], 1u);
         }
         __syncthreads();
         // ---- C: creation ranks
@@ -572,16 +583,25 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
             __syncthreads();
             nmtot = (int)qt_block_scan(t0, t2, size, sh);
         } else {
-            // careful phase: order candidates by descending (count, creation rank)
-            for (int p = tid; p < size; p += QT_THREADS) {
-                uint32_t rank = 0xffffffffu;
-                if ((meta[p] >> 16) & 1) {
-                    const uint32_t key = (cnt[p] << 16) | (meta[p] & 0xffffu);
-                    rank = 0;
-                    for (int o = 0; o < size; ++o)
-                        if (((meta[o] >> 16) & 1) && ((cnt[o] << 16) | (meta[o] & 0xffffu)) > key) ++rank;
+            // careful phase: order candidates by descending (count, creation rank).  The candidate keys are first
+            // compacted into a dense, 16-byte aligned LDS array (scratch = newpos, rewritten in phase D anyway); each
+            // candidate then counts the larger keys with ds_read_b128 over M/4 steps instead of walking the whole list.
+            uint32_t *dk = newpos, *dp = newpos + 2 * (size_t)ncap;   // dense keys [M + 4], back references [M]
+            for (int p = tid; p < size; p += QT_THREADS) { t0[p] = (meta[p] >> 16) & 1; t3[p] = 0xffffffffu; }
+            __syncthreads();
+            const int Mc = (int)qt_block_scan(t0, t1, size, sh);
+            for (int p = tid; p < size; p += QT_THREADS)
+                if ((meta[p] >> 16) & 1) { dk[t1[p]] = (cnt[p] << 16) | (meta[p] & 0xffffu); dp[t1[p]] = p; }
+            if (tid < 4) dk[Mc + tid] = 0u;   // padding compares as "not larger"
+            __syncthreads();
+            for (int i = tid; i < Mc; i += QT_THREADS) {
+                const uint32_t key = dk[i];
+                uint32_t rank = 0;
+                for (int j = 0; j < Mc; j += 4) {
+                    const uint4 v = *(const uint4 *)(dk + j);
+                    rank += (v.x > key) + (v.y > key) + (v.z > key) + (v.w > key);
                 }
-                t3[p] = rank;
+                t3[dp[i]] = rank;
             }
             if (tid == 0) { sh->m = 0; sh->jstar = 0x7fffffff; }
             __syncthreads();
@@ -642,7 +662,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
         // ---- E: keys follow their node
         for (int k = tid; k < K; k += QT_THREADS) {
             const int p = knode[k];
-            const int q = ((meta[p] >> 16) & 1) ? qt_quadrant(cand[k].x, box0[p], box1[p]) : 0;
+            const int q = ((meta[p] >> 16) & 1) ? qt_quadrant(QT_KPOS(k), box0[p], box1[p]) : 0;
             knode[k] = (uint16_t)newpos[4 * p + q];
         }
         __syncthreads();
@@ -1196,7 +1216,7 @@ hipError_t orbx_upload_pattern() {
 }
 
 size_t orbx_quadtree_smem(int ncap, int lds_keys) {
-    return 128 + 4 * QT_THREADS + (size_t)ncap * (8 + 8 * 4 + 16 + 16 + 6 * 4) + (size_t)lds_keys * 2 + 16;
+    return 128 + 4 * QT_THREADS + (size_t)ncap * (8 + 8 * 4 + 16 + 16 + 6 * 4) + (size_t)lds_keys * 6 + 16;
 }
 
 void orbx_launch_clear(hipStream_t s, int *a, int na, int *b, int nb, int *c, int nc) {
