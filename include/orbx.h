@@ -100,6 +100,13 @@ orbx_status orbx_extract_batch_device(orbx_handle *h, int nframes, const uint8_t
                                       orbx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts,
                                       int32_t *d_status, int cap);
 
+/* Pixel format of the frames given to the three extract entry points (default ORBX_FMT_GRAY8).  The colour formats
+ * fuse the cv::cvtColor(CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) that Tracking::GrabImage* runs before
+ * the extractor (src/Tracking.cc:245-271, 302-320, 372-385; mbRGB selects the RGB variants) into level 0:
+ * gray = (R*4899 + G*9617 + B*1868 + 8192) >> 14 (OpenCV 3.2, 8-bit).  `stride` stays in bytes, `width` in pixels. */
+enum { ORBX_FMT_GRAY8 = 0, ORBX_FMT_RGB8 = 1, ORBX_FMT_BGR8 = 2, ORBX_FMT_RGBA8 = 3, ORBX_FMT_BGRA8 = 4 };
+orbx_status orbx_set_input_format(orbx_handle *h, int pixel_format);
+
 /* ---- pyramid access: replaces the public member `mvImagePyramid` (include/ORBextractor.h:185),
  *      read by Frame::ComputeStereoMatches (src/Frame.cc:910,1040,1072,1079).  Valid until the next
  *      extract on this handle ("pyramid is overwritten every frame", include/ORBextractor.h:30-35). -- */

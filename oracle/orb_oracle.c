@@ -794,3 +794,15 @@ void orc_three_maxima(const int *hs, int L, int *ind1, int *ind2, int *ind3) {
     if (max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
     else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
 }
+
+/* cv::cvtColor(.., CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY), 8-bit (OpenCV 3.2 RGB2Gray<uchar>:
+ * coefficients R2Y = 4899, G2Y = 9617, B2Y = 1868, yuv_shift = 14, rounding term 1 << 13); the conversion
+ * Tracking::GrabImage* applies before the extractor (src/Tracking.cc:245-271, 302-320, 372-385). */
+void orc_cvt_gray(const uint8_t *src, int w, int h, int sstride, int nch, int rgb_order, uint8_t *dst, int dstride) {
+    const int ro = rgb_order ? 0 : 2, bo = rgb_order ? 2 : 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const uint8_t *p = src + (size_t)y * sstride + (size_t)x * nch;
+            dst[(size_t)y * dstride + x] = (uint8_t)((p[ro] * 4899 + p[1] * 9617 + p[bo] * 1868 + (1 << 13)) >> 14);
+        }
+}

@@ -75,6 +75,7 @@ void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int sstride,
 int orc_fast9_16(const uint8_t *img, int w, int h, int stride, int threshold,
                  orc_keypoint *out, int cap);
 void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride);
+void orc_cvt_gray(const uint8_t *src, int w, int h, int sstride, int nch, int rgb_order, uint8_t *dst, int dstride);
 float orc_fast_atan2(float y, float x);
 int orc_cv_round_f(float v);
 /* quadtree on its own: keys in (x,y,response); returns count, writes selected input indices

@@ -80,6 +80,7 @@ def lib():
         L.orc_search_by_projection_mp.restype = C.c_int
         L.orc_search_by_projection_mp.argtypes = ([C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_int] +
                                                   [C.c_void_p] * 6 + [C.c_float, C.c_float, C.c_void_p])
+        L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -272,3 +273,12 @@ def search_by_projection_mp(kf, df, u_right, frame_obs, bounds, scale, in_view, 
                                           _p(scale), len(in_view), _p(in_view), _p(proj), _p(level), _p(view_cos), _p(mpdesc),
                                           _p(mp_obs), th, nnratio, _p(out))
     return n, out[:len(kf)].copy()
+
+
+def cvt_gray(img, rgb_order=True):
+    """cv::cvtColor to gray for HxWx3 / HxWx4 uint8 images (rgb_order False = BGR / BGRA)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, c = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_cvt_gray(_p(img), w, h, img.strides[0], c, int(rgb_order), _p(out), w)
+    return out

@@ -14,6 +14,7 @@ assert KP_DTYPE.itemsize == 28
 
 OK, EMPTY_IMAGE, BAD_ARGUMENT, BAD_ASPECT, CAPACITY, HIP_ERROR, NO_DEVICE, UNSUPPORTED = range(8)
 FP_GCC_FMA, FP_STRICT = 0, 1
+FMT_GRAY8, FMT_RGB8, FMT_BGR8, FMT_RGBA8, FMT_BGRA8 = range(5)
 K_NAMES = ("k_pyr_l0", "k_pyr_resize", "k_fast_cells", "k_quadtree", "k_orient", "k_blur", "k_describe",
            "k_match", "misc")
 K_COUNT = len(K_NAMES)
@@ -60,7 +61,7 @@ SYMBOLS = [
     "orbx_kernel_name", "orbx_debug_candidates", "orbx_debug_level_keypoints", "orbx_debug_blur_copy",
     "orbx_grid_create", "orbx_grid_destroy", "orbx_grid_query", "orbx_three_maxima",
     "orbx_search_for_initialization", "orbx_stereo_match", "orbx_search_by_projection_frame",
-    "orbx_search_by_projection_mappoints",
+    "orbx_search_by_projection_mappoints", "orbx_set_input_format",
 ]
 
 _lib = None
@@ -125,6 +126,7 @@ def lib():
     L.orbx_search_by_projection_mappoints.restype = i32
     L.orbx_search_by_projection_mappoints.argtypes = [vp, C.POINTER(FrameView), vp, C.POINTER(MapPointView), f32, f32, vp,
                                                       C.POINTER(i32)]
+    L.orbx_set_input_format.restype = i32; L.orbx_set_input_format.argtypes = [vp, i32]
     _lib = L
     return L
 

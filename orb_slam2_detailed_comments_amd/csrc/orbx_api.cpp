@@ -54,6 +54,7 @@ struct orbx_handle {
     int last_batch = 0;
     int mk_w = 0, mk_h = 0, mk_total = 0;   // orbx_max_keypoints cache
     void *d_match_ws = nullptr; size_t match_ws_bytes = 0;   // partial (best, second) keys of k_match
+    int input_format = ORBX_FMT_GRAY8;        // pixel format of the frames handed to the extract entry points
     bool blur_valid = false;                // d_blur holds the blurred pyramid of the last batch
     // profiling
     uint32_t prof_mask = 0;
@@ -290,6 +291,13 @@ extern "C" int orbx_max_keypoints(orbx_handle *h, int width, int height) {
 }
 
 // ---------------------------------------------------------------- extraction
+static inline int orbx_fmt_channels(int fmt) { return fmt == ORBX_FMT_GRAY8 ? 1 : (fmt == ORBX_FMT_RGB8 || fmt == ORBX_FMT_BGR8) ? 3 : 4; }
+extern "C" orbx_status orbx_set_input_format(orbx_handle *h, int pixel_format) {
+    if (!h) return fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (pixel_format < ORBX_FMT_GRAY8 || pixel_format > ORBX_FMT_BGRA8) return fail(ORBX_BAD_ARGUMENT, "unknown pixel format");
+    h->input_format = pixel_format;
+    return ORBX_OK;
+}
 static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W, int H, int stride,
                              int64_t frame_stride, orbx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_counts,
                              int32_t *d_status, int cap) {
@@ -302,7 +310,13 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
     // l+1 -- was measured and rejected: 81 k frames/s against 116 k for this single in-order sequence; the cross-stream
     // event waits and the 8 small FAST launches cost more than the overlap recovers.)
     { ProfScope ps(h, ORBX_K_PYR_L0);
-      orbx_launch_pyr_l0(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr); }
+      if (h->input_format == ORBX_FMT_GRAY8) {
+          orbx_launch_pyr_l0(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr);
+      } else {   // cvtColor of Tracking::GrabImage* fused into level 0
+          const int nch = (h->input_format == ORBX_FMT_RGB8 || h->input_format == ORBX_FMT_BGR8) ? 3 : 4;
+          const bool rgb = h->input_format == ORBX_FMT_RGB8 || h->input_format == ORBX_FMT_RGBA8;
+          orbx_launch_pyr_l0_color(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, nch, rgb ? 0 : 2, rgb ? 2 : 0);
+      } }
     for (int l = 1; l < NL; ++l) {
         ProfScope ps(h, ORBX_K_PYR_RESIZE);
         orbx_launch_pyr_resize(s, g, B, l, h->d_taps, h->d_pyr);
@@ -329,7 +343,7 @@ extern "C" orbx_status orbx_extract_batch_device(orbx_handle *h, int nframes, co
                                                  uint8_t *d_desc, int32_t *d_counts, int32_t *d_status, int cap) {
     if (!h) return fail(ORBX_BAD_ARGUMENT, "null handle");
     if (!d_imgs || width <= 0 || height <= 0 || nframes <= 0) return fail(ORBX_EMPTY_IMAGE, "empty image");
-    if (!d_kps || !d_desc || !d_counts || cap <= 0 || stride < width) return fail(ORBX_BAD_ARGUMENT, "bad output buffers / stride");
+    if (!d_kps || !d_desc || !d_counts || cap <= 0 || stride < width * orbx_fmt_channels(h->input_format)) return fail(ORBX_BAD_ARGUMENT, "bad output buffers / stride");
     orbx_status st = configure(h, width, height);
     if (st != ORBX_OK) return st;
     HIPCHK(hipSetDevice(h->dev));
@@ -369,7 +383,7 @@ extern "C" orbx_status orbx_extract_batch(orbx_handle *h, int nframes, const uin
                                           int32_t *counts, int cap) {
     if (!h) return fail(ORBX_BAD_ARGUMENT, "null handle");
     if (!imgs || width <= 0 || height <= 0 || nframes <= 0) return fail(ORBX_EMPTY_IMAGE, "empty image");
-    if (!kps || !desc || !counts || cap <= 0 || stride < width) return fail(ORBX_BAD_ARGUMENT, "bad output buffers / stride");
+    if (!kps || !desc || !counts || cap <= 0 || stride < width * orbx_fmt_channels(h->input_format)) return fail(ORBX_BAD_ARGUMENT, "bad output buffers / stride");
     orbx_status st = configure(h, width, height);
     if (st != ORBX_OK) return st;
     HIPCHK(hipSetDevice(h->dev));

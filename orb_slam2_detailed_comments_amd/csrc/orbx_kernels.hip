@@ -65,6 +65,32 @@ __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restri
     }
 }
 
+// K0c: level 0 straight from an interleaved colour frame: cv::cvtColor(CV_RGB2GRAY / BGR / RGBA / BGRA) of
+// Tracking::GrabImage* (reference src/Tracking.cc:245-271, 302-320, 372-385) fused into the border kernel.
+// OpenCV 3.2 8-bit formula: gray = (R*4899 + G*9617 + B*1868 + 8192) >> 14.  thread = 4 padded pixels.
+__global__ __launch_bounds__(256) void k_pyr_l0_color(DGeom g, const uint8_t *__restrict__ imgs, int W, int H, int stride,
+                                                      long long frame_stride, uint8_t *__restrict__ pyr, int nch,
+                                                      int r_off, int b_off) {
+    const DLevel &L = g.lv[0];
+    const int X = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int Y = blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (X >= L.pw || Y >= L.ph) return;
+    const uint8_t *src = imgs + (long long)f * frame_stride + (long long)orbx_reflect101(Y - ORBX_EDGE, H) * stride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = X + i;
+        uint32_t p = 0;
+        if (x < L.pw) {
+            const uint8_t *px = src + (long long)orbx_reflect101(x - ORBX_EDGE, W) * nch;
+            p = (uint32_t)(px[r_off] * 4899 + px[1] * 9617 + px[b_off] * 1868 + 8192) >> 14;
+        }
+        v |= p << (8 * i);
+    }
+    *(uint32_t *)(pyr + (long long)f * g.pyr_bytes + L.off + (long long)Y * L.pitch + X) = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: level l = cv::resize(INTER_LINEAR) of the PADDED level l-1 into the centre + reflect-101 border,
 // in one pass: the border is produced by evaluating the bilinear formula at the reflected coordinate
@@ -1232,6 +1258,12 @@ void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *img
     const int icols = (xe - 32 + 1023) / 1024;
     dim3 grid(icols + 1, (L.ph + 4 * L0_ROWS - 1) / (4 * L0_ROWS), B);
     hipLaunchKernelGGL(k_pyr_l0, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, xe);
+}
+void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
+                              long long frame_stride, uint8_t *pyr, int nch, int r_off, int b_off) {
+    const DLevel &L = g.lv[0];
+    dim3 grid((L.pw + 255) / 256, (L.ph + 3) / 4, B);
+    hipLaunchKernelGGL(k_pyr_l0_color, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, nch, r_off, b_off);
 }
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr) {
     const DLevel &L = g.lv[level];

@@ -9,6 +9,8 @@ hipError_t orbx_quadtree_prepare(size_t smem);
 void orbx_launch_clear(hipStream_t s, int *a, int na, int *b, int nb, int *c, int nc);
 void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
                         long long frame_stride, uint8_t *pyr);
+void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
+                              long long frame_stride, uint8_t *pyr, int nch, int r_off, int b_off);
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr);
 void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint8_t *pyr, uint2 *cand,
                       int *cell_count, int max_cw, int max_ch, int cell_begin, int cell_end);

@@ -78,6 +78,11 @@ class ORBextractor:
             raise _capi.OrbxError(-n, self._L.orbx_last_error().decode())
         return n
 
+    def set_input_format(self, fmt):
+        """_capi.FMT_*: colour frames are converted on the device exactly like cv::cvtColor in Tracking::GrabImage*"""
+        check(self._L.orbx_set_input_format(self._h, int(fmt)))
+        self._nch = 1 if fmt == _capi.FMT_GRAY8 else 3 if fmt in (_capi.FMT_RGB8, _capi.FMT_BGR8) else 4
+
     # ---- operator()
     def __call__(self, image, mask=None):
         """image: HxW uint8.  Returns (keypoints[KP_DTYPE], descriptors[N,32] uint8).
@@ -85,8 +90,10 @@ class ORBextractor:
         if image is None or image.size == 0:
             return None, None
         img = np.ascontiguousarray(image)
-        assert img.dtype == np.uint8 and img.ndim == 2, "image.type() == CV_8UC1 (src/ORBextractor.cc:1972)"
-        h, w = img.shape
+        nch = getattr(self, "_nch", 1)
+        assert img.dtype == np.uint8 and (img.ndim == 2 if nch == 1 else (img.ndim == 3 and img.shape[2] == nch)), \
+            "image.type() == CV_8UC1 (src/ORBextractor.cc:1972), or the colour format set with set_input_format"
+        h, w = img.shape[:2]
         cap = self.max_keypoints(w, h)
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)

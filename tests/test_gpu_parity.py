@@ -286,3 +286,23 @@ def test_bench_line_contract():
         assert k in j
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "u8" and j["value"] > 1000
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
+
+
+@pytest.mark.parametrize("fmt,nch,rgb", [(_capi.FMT_RGB8, 3, True), (_capi.FMT_BGR8, 3, False), (_capi.FMT_RGBA8, 4, True),
+                                         (_capi.FMT_BGRA8, 4, False)])
+def test_colour_input_fused_cvtcolor(fmt, nch, rgb):
+    """Tracking::GrabImage* converts colour frames with cv::cvtColor before the extractor (src/Tracking.cc:245-271);
+    the device path fuses that conversion into level 0"""
+    rng = np.random.default_rng(nch + int(rgb))
+    gray = synth.stream(320, 240, 1, stream_id=15)[0].astype(np.int32)
+    col = np.stack([np.clip(gray + rng.integers(-30, 31, gray.shape), 0, 255) for _ in range(nch)], 2).astype(np.uint8)
+    ex = ORBextractor(500)
+    ex.set_input_format(fmt)
+    k, d = ex(col)
+    g = oracle.cvt_gray(col, rgb)
+    orc = oracle.OracleExtractor(500)
+    out = orc.extract(g)
+    assert np.array_equal(ex.pyramid_level(0), orc.level_image(0))
+    assert_frame_equal((k, d), out, f"fmt {fmt}")
+    ex.set_input_format(_capi.FMT_GRAY8)
+    assert_frame_equal(ex(g), out, "gray again")

@@ -142,3 +142,14 @@ def test_match_bruteforce_bookkeeping():
     assert bi[5] == 10 and bd[5] == 0 and sd[5] == 0
     bi, bd, sd = oracle.match_bruteforce(q, t[:0])
     assert (bi == -1).all() and (bd == 0x7fffffff).all()
+
+
+def test_cvt_gray_formula():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (7, 9, 3)).astype(np.uint8)
+    r, g, b = (img[..., i].astype(np.int64) for i in range(3))
+    exp = ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(oracle.cvt_gray(img, True), exp)
+    assert np.array_equal(oracle.cvt_gray(img[..., ::-1], False), exp)
+    white = np.full((2, 2, 4), 255, np.uint8)
+    assert (oracle.cvt_gray(white, True) == 255).all()          # the three weights sum to 16384
