@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void k_pyr_l0_color(DGeom g, const uint8_t *__
 __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const OrbxTap *__restrict__ taps,
                                                     uint8_t *__restrict__ pyr) {
     // block = 64 x 4 threads; thread = 4 horizontally adjacent destination pixels x RS_ROWS rows (dword stores).
+    // Products are written with __mul24 (weights <= 2048, T >> 4 <= 32640): v_mul_lo_u32 is a quarter-rate instruction.
     // The <= 8 source pixels a thread needs per source row sit inside 3 aligned dwords: 6 dword loads per
     // destination row replace 16 byte gathers (byte-gather fallback for exotic scale factors whose footprint
     // exceeds 12 bytes).
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const Or
                 const uint32_t pw_ = __builtin_amdgcn_alignbyte(whi, wlo, (uint32_t)idx & 3u);
                 const int T0 = (int)(pu & 0xff) * tx[i].a0 + (int)((pu >> 8) & 0xff) * tx[i].a1;
                 const int T1 = (int)(pw_ & 0xff) * tx[i].a0 + (int)((pw_ >> 8) & 0xff) * tx[i].a1;
-                const uint32_t p = (uint32_t)((((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+                const uint32_t p = (uint32_t)((((((b0 & 0xfff) * ((T0 >> 4) & 0xffff))) >> 16) + ((((b1 & 0xfff) * ((T1 >> 4) & 0xffff))) >> 16) + 2) >> 2) & 0xffu;
                 v |= p << (8 * i);
             }
         } else {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const Or
             for (int i = 0; i < 4; ++i) {
                 const int T0 = r0[tx[i].s0] * tx[i].a0 + r0[tx[i].s1] * tx[i].a1;
                 const int T1 = r1[tx[i].s0] * tx[i].a0 + r1[tx[i].s1] * tx[i].a1;
-                const uint32_t p = (uint32_t)((((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+                const uint32_t p = (uint32_t)((((((b0 & 0xfff) * ((T0 >> 4) & 0xffff))) >> 16) + ((((b1 & 0xfff) * ((T1 >> 4) & 0xffff))) >> 16) + 2) >> 2) & 0xffu;
                 v |= p << (8 * i);
             }
         }
