@@ -54,6 +54,9 @@ struct orbx_handle {
     int last_batch = 0;
     int mk_w = 0, mk_h = 0, mk_total = 0;   // orbx_max_keypoints cache
     void *d_match_ws = nullptr; size_t match_ws_bytes = 0;   // partial (best, second) keys of k_match
+    // grow-only scratch arena for the host-buffer convenience entry points (match / matrix / stereo): no hipMalloc
+    // on the steady-state path and nothing to leak on an error return
+    uint8_t *d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
     int input_format = ORBX_FMT_GRAY8;        // pixel format of the frames handed to the extract entry points
     bool blur_valid = false;                // d_blur holds the blurred pyramid of the last batch
     // profiling
@@ -249,7 +252,7 @@ extern "C" void orbx_destroy(orbx_handle *h) {
         prof_drain(h);
         for (auto e : h->pool) hipEventDestroy(e);
         free_geometry_buffers(h);
-        hipFree(h->d_match_ws);
+        hipFree(h->d_match_ws); hipFree(h->d_scratch);
         hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_ustatus);
         if (h->own_stream) hipStreamDestroy(h->own_stream);
     }
@@ -522,6 +525,24 @@ extern "C" orbx_status orbx_debug_level_keypoints(orbx_handle *h, int frame, int
     return ORBX_OK;
 }
 
+// ---------------------------------------------------------------- scratch arena
+static orbx_status scratch_reserve(orbx_handle *h, size_t bytes) {
+    h->scratch_used = 0;
+    if (bytes <= h->scratch_bytes) return ORBX_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(h->d_scratch); h->d_scratch = nullptr; h->scratch_bytes = 0;
+    const size_t want = std::max(bytes, (size_t)1 << 20);
+    HIPCHK(hipMalloc(&h->d_scratch, want));
+    h->scratch_bytes = want;
+    return ORBX_OK;
+}
+template <typename T> static T *scratch_take(orbx_handle *h, size_t count) {
+    T *p = (T *)(h->d_scratch + h->scratch_used);
+    h->scratch_used += (count * sizeof(T) + 255) & ~(size_t)255;
+    return p;
+}
+static inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 // ---------------------------------------------------------------- matching
 extern "C" orbx_status orbx_match_bruteforce_device(orbx_handle *h, int npairs, const uint8_t *d_q, const int32_t *d_nq,
                                                     int64_t q_stride, const uint8_t *d_t, const int32_t *d_nt,
@@ -553,23 +574,22 @@ extern "C" orbx_status orbx_match_bruteforce(orbx_handle *h, const uint8_t *q, i
         return fail(ORBX_BAD_ARGUMENT, "bad argument");
     if (nq == 0) return ORBX_OK;
     HIPCHK(hipSetDevice(h->dev));
-    uint8_t *dq = nullptr, *dt = nullptr; int *dn = nullptr, *dout = nullptr;
-    HIPCHK(hipMalloc(&dq, (size_t)nq * 32));
-    HIPCHK(hipMalloc(&dt, (size_t)std::max(nt, 1) * 32));
-    HIPCHK(hipMalloc(&dn, 2 * sizeof(int)));
-    HIPCHK(hipMalloc(&dout, (size_t)3 * nq * sizeof(int)));
+    orbx_status st = scratch_reserve(h, pad256((size_t)nq * 32) + pad256((size_t)std::max(nt, 1) * 32) + 256 +
+                                            pad256((size_t)3 * nq * sizeof(int)));
+    if (st != ORBX_OK) return st;
+    uint8_t *dq = scratch_take<uint8_t>(h, (size_t)nq * 32), *dt = scratch_take<uint8_t>(h, (size_t)std::max(nt, 1) * 32);
+    int *dn = scratch_take<int>(h, 2), *dout = scratch_take<int>(h, (size_t)3 * nq);
     int hn[2] = {nq, nt};
-    HIPCHK(hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice));
-    if (nt > 0) HIPCHK(hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dn, hn, sizeof(hn), hipMemcpyHostToDevice));
-    orbx_status st = orbx_match_bruteforce_device(h, 1, dq, dn, 0, dt, dn + 1, 0, dout, dout + nq, dout + 2 * nq, nq);
+    HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, h->stream));
+    if (nt > 0) HIPCHK(hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dn, hn, sizeof(hn), hipMemcpyHostToDevice, h->stream));
+    st = orbx_match_bruteforce_device(h, 1, dq, dn, 0, dt, dn + 1, 0, dout, dout + nq, dout + 2 * nq, nq);
     if (st == ORBX_OK) {
-        hipStreamSynchronize(h->stream);
-        hipMemcpy(best_idx, dout, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
-        hipMemcpy(best_dist, dout + nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
-        hipMemcpy(second_dist, dout + 2 * nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost);
+        HIPCHK(hipMemcpyAsync(best_idx, dout, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(best_dist, dout + nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(second_dist, dout + 2 * nq, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));   // also keeps hn[] alive until the H2D copy has been consumed
     }
-    hipFree(dq); hipFree(dt); hipFree(dn); hipFree(dout);
     return st;
 }
 
@@ -579,17 +599,16 @@ extern "C" orbx_status orbx_hamming_matrix(orbx_handle *h, const uint8_t *q, int
     if (nq <= 0 || nt <= 0) return ORBX_OK;
     if (!q || !t || !dist) return fail(ORBX_BAD_ARGUMENT, "null argument");
     HIPCHK(hipSetDevice(h->dev));
-    uint8_t *dq = nullptr, *dt = nullptr; uint16_t *dd = nullptr;
-    HIPCHK(hipMalloc(&dq, (size_t)nq * 32));
-    HIPCHK(hipMalloc(&dt, (size_t)nt * 32));
-    HIPCHK(hipMalloc(&dd, (size_t)nq * nt * sizeof(uint16_t)));
-    HIPCHK(hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice));
+    orbx_status st = scratch_reserve(h, pad256((size_t)nq * 32) + pad256((size_t)nt * 32) + pad256((size_t)nq * nt * sizeof(uint16_t)));
+    if (st != ORBX_OK) return st;
+    uint8_t *dq = scratch_take<uint8_t>(h, (size_t)nq * 32), *dt = scratch_take<uint8_t>(h, (size_t)nt * 32);
+    uint16_t *dd = scratch_take<uint16_t>(h, (size_t)nq * nt);
+    HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, h->stream));
     { ProfScope ps(h, ORBX_K_MATCH);
       orbx_launch_hamming_matrix(h->stream, dq, nq, dt, nt, dd); }
-    hipError_t e = hipStreamSynchronize(h->stream);
-    if (e == hipSuccess) e = hipMemcpy(dist, dd, (size_t)nq * nt * sizeof(uint16_t), hipMemcpyDeviceToHost);
-    hipFree(dq); hipFree(dt); hipFree(dd);
+    hipError_t e = hipMemcpyAsync(dist, dd, (size_t)nq * nt * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
     return ORBX_OK;
 }
@@ -820,15 +839,16 @@ extern "C" orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int f
         sg.pw[l] = hl->geom.lv[l].pw; sg.ph[l] = hl->geom.lv[l].ph; sg.pitch[l] = hl->geom.lv[l].pitch;
         sg.off[l] = hl->geom.lv[l].off;
     }
-    orbx_keypoint *dkl = nullptr, *dkr = nullptr; uint8_t *ddl = nullptr, *ddr = nullptr;
-    float *du = nullptr, *dz = nullptr; int *dsad = nullptr;
-    HIPCHK(hipMalloc(&dkl, (size_t)nl * sizeof(orbx_keypoint)));
-    HIPCHK(hipMalloc(&ddl, (size_t)nl * 32));
-    HIPCHK(hipMalloc(&dkr, (size_t)std::max(nr, 1) * sizeof(orbx_keypoint)));
-    HIPCHK(hipMalloc(&ddr, (size_t)std::max(nr, 1) * 32));
-    HIPCHK(hipMalloc(&du, (size_t)nl * sizeof(float)));
-    HIPCHK(hipMalloc(&dz, (size_t)nl * sizeof(float)));
-    HIPCHK(hipMalloc(&dsad, (size_t)nl * sizeof(int)));
+    st = scratch_reserve(hl, pad256((size_t)nl * sizeof(orbx_keypoint)) + pad256((size_t)nl * 32) +
+                                 pad256((size_t)std::max(nr, 1) * sizeof(orbx_keypoint)) + pad256((size_t)std::max(nr, 1) * 32) +
+                                 3 * pad256((size_t)nl * sizeof(float)));
+    if (st != ORBX_OK) return st;
+    orbx_keypoint *dkl = scratch_take<orbx_keypoint>(hl, nl);
+    uint8_t *ddl = scratch_take<uint8_t>(hl, (size_t)nl * 32);
+    orbx_keypoint *dkr = scratch_take<orbx_keypoint>(hl, std::max(nr, 1));
+    uint8_t *ddr = scratch_take<uint8_t>(hl, (size_t)std::max(nr, 1) * 32);
+    float *du = scratch_take<float>(hl, nl), *dz = scratch_take<float>(hl, nl);
+    int *dsad = scratch_take<int>(hl, nl);
     HIPCHK(hipMemcpyAsync(dkl, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, hl->stream));
     HIPCHK(hipMemcpyAsync(ddl, dl, (size_t)nl * 32, hipMemcpyHostToDevice, hl->stream));
     if (nr > 0) {
@@ -843,7 +863,6 @@ extern "C" orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int f
     HIPCHK(hipMemcpyAsync(depth, dz, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, hl->stream));
     HIPCHK(hipMemcpyAsync(sad.data(), dsad, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, hl->stream));
     hipError_t e = hipStreamSynchronize(hl->stream);
-    hipFree(dkl); hipFree(ddl); hipFree(dkr); hipFree(ddr); hipFree(du); hipFree(dz); hipFree(dsad);
     if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
     // median cut (:1160-1175): sort (SAD, index), drop everything at or above 1.5 * 1.4 * median
     std::vector<std::pair<int, int>> v;

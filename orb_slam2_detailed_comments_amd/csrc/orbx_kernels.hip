@@ -992,15 +992,17 @@ __global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__rest
             const uint16_t *hp = hrow + (iy + DS_R - 3) * DS_HC + (ix + DS_R - 3);
             const int r0 = hp[3 * DS_HC], r1 = hp[2 * DS_HC] + hp[4 * DS_HC], r2 = hp[1 * DS_HC] + hp[5 * DS_HC],
                       r3 = hp[0] + hp[6 * DS_HC];
-            int o;
-            if (x + ix < wvec) {
-                float s0 = (float)r0 * k0 + 0.f;
-                s0 = s0 + (float)r1 * k1;
-                s0 = s0 + (float)r2 * k2;
-                s0 = s0 + (float)r3 * k3;
-                o = (int)__builtin_rintf(s0);
-            } else {
-                o = (55 * r0 + 49 * r1 + 34 * r2 + 18 * r3 + (1 << 15)) >> 16;
+            // float column path for every lane; the integer tail (last w & 3 columns of the level) is evaluated only
+            // when some lane of the wave actually samples such a column (wave-uniform branch, almost never taken)
+            float s0 = (float)r0 * k0 + 0.f;
+            s0 = s0 + (float)r1 * k1;
+            s0 = s0 + (float)r2 * k2;
+            s0 = s0 + (float)r3 * k3;
+            int o = (int)__builtin_rintf(s0);
+            const bool tail = x + ix >= wvec;
+            if (__ballot(tail) != 0ull) {
+                const int oi2 = (55 * r0 + 49 * r1 + 34 * r2 + 18 * r3 + (1 << 15)) >> 16;
+                o = tail ? oi2 : o;
             }
             tv[2 * r + s2] = min(max(o, 0), 255);
         }

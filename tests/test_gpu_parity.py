@@ -306,3 +306,21 @@ def test_colour_input_fused_cvtcolor(fmt, nch, rgb):
     assert_frame_equal((k, d), out, f"fmt {fmt}")
     ex.set_input_format(_capi.FMT_GRAY8)
     assert_frame_equal(ex(g), out, "gray again")
+
+
+@pytest.mark.parametrize("w,h,nf", [(40, 40, 50), (64, 48, 100), (33, 65, 40), (700, 351, 300)])
+def test_tiny_and_odd_geometries(w, h, nf):
+    """smallest geometries the cell grid admits (40x40), levels with no FAST cell at all, aspect close to
+    the nIni rounding boundary"""
+    rng = np.random.default_rng(w * 1000 + h)
+    img = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    img[h // 4: h // 2, w // 4: w // 2] = 240
+    ex = ORBextractor(nf)
+    orc = oracle.OracleExtractor(nf)
+    out = orc.extract(img, cap=4096)
+    if out[0] < 0:
+        with pytest.raises(OrbxError):
+            ex(img)
+        return
+    assert_frame_equal(ex(img), out, f"{w}x{h}")
+    check_stages(ex, orc, 0)
