@@ -184,7 +184,6 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     HIPCHK(orbx_quadtree_prepare(orbx_quadtree_smem(h->ncap, h->lds_keys)));
     // buffers
     HIPCHK(hipMalloc(&h->d_pyr, (size_t)B * g.pyr_bytes + 256));   // +256: kernels read whole aligned dwords
-    HIPCHK(hipMalloc(&h->d_blur, (size_t)B * g.pyr_bytes + 256));
     HIPCHK(hipMalloc(&h->d_cells, std::max<size_t>(1, g.cells.size()) * sizeof(OrbxCell)));
     HIPCHK(hipMalloc(&h->d_taps, std::max<size_t>(1, g.taps.size()) * sizeof(OrbxTap)));
     HIPCHK(hipMalloc(&h->d_cand, (size_t)B * g.cand_total * sizeof(uint2)));
@@ -201,7 +200,6 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     if (!g.taps.empty())
         HIPCHK(hipMemcpy(h->d_taps, g.taps.data(), g.taps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(h->d_pyr, 0, (size_t)B * g.pyr_bytes));
-    HIPCHK(hipMemset(h->d_blur, 0, (size_t)B * g.pyr_bytes));
     HIPCHK(hipMemset(h->d_lvl_count, 0, (size_t)B * NL * sizeof(int)));
     HIPCHK(hipMemset(h->d_cand_count, 0, (size_t)B * NL * sizeof(int)));
     h->configured = true;
@@ -467,6 +465,10 @@ extern "C" orbx_status orbx_debug_blur_copy(orbx_handle *h, int frame, int level
     if (st != ORBX_OK) return st;
     if (!h->blur_valid) {  // stand-alone k_blur over the resident pyramid (same arithmetic as the fused path)
         HIPCHK(hipSetDevice(h->dev));
+        if (!h->d_blur) {      // the blurred slab only exists for inspection: allocated on first request
+            HIPCHK(hipMalloc(&h->d_blur, (size_t)h->p.max_batch * h->geom.pyr_bytes + 256));
+            HIPCHK(hipMemset(h->d_blur, 0, (size_t)h->p.max_batch * h->geom.pyr_bytes));
+        }
         { ProfScope ps(h, ORBX_K_BLUR);
           orbx_launch_blur(h->stream, h->dg, h->last_batch, h->d_pyr, h->d_blur); }
         h->blur_valid = true;

@@ -324,3 +324,18 @@ def test_tiny_and_odd_geometries(w, h, nf):
         return
     assert_frame_equal(ex(img), out, f"{w}x{h}")
     check_stages(ex, orc, 0)
+
+
+@pytest.mark.parametrize("nf,sf,nl,ini,mn", [(700, 1.5, 5, 20, 7), (300, 2.0, 4, 30, 10), (1000, 1.1, 12, 20, 7),
+                                             (500, 1.2, 8, 12, 12), (800, 1.2, 1, 20, 7), (600, 1.3, 8, 40, 5)])
+def test_other_extractor_parameters(nf, sf, nl, ini, mn):
+    """the five constructor arguments are free parameters (YAML, src/Tracking.cc:160-168): other scale factors
+    (incl. the byte-gather fallback of the resize kernel), level counts, and iniThFAST == minThFAST (no retry)"""
+    frames = synth.stream(640, 480, 2, stream_id=40 + nl)
+    ex = ORBextractor(nf, sf, nl, ini, mn, max_batch=2)
+    orc = oracle.OracleExtractor(nf, sf, nl, ini, mn)
+    res = ex.extract_batch(frames)
+    for f in range(2):
+        out = orc.extract(frames[f], cap=ex.max_keypoints(640, 480))
+        check_stages(ex, orc, f, nlevels=nl)
+        assert_frame_equal(res[f], out, f"params {nf},{sf},{nl},{ini},{mn} frame {f}")
