@@ -193,14 +193,19 @@ __device__ __forceinline__ void orbx_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#define FAST_CPW 4      // cells per wave: prologue amortised, next tile prefetched into registers during compute
+#ifndef FAST_CPW
+#define FAST_CPW 2      // cells per wave (2 measured best of 1,2,4,8): prologue amortised, next tile prefetched into registers during compute
+#endif
+#ifndef FAST_WPS
+#define FAST_WPS 5      // __launch_bounds__ waves per SIMD (caps VGPRs at 96)
+#endif
 #define FAST_PF 10      // prefetch registers: 4 rows x 16 dwords per step -> cells up to 40 rows x 61 px (all but tiny levels)
 
 // FAST_TP (LDS tile pitch) is a template constant: row offsets become shifts/immediates instead of the quarter-rate
 // v_mul_lo_u32, and the 16 ring offsets fold into the ds_read offset field.  44 covers cells up to 38 px wide
 // (every level of the usual geometries), 72 the widest cells of tiny pyramid levels.
 template <int FAST_TP>
-__global__ __launch_bounds__(64, 5) void k_fast_cells(DGeom g, const OrbxCell *__restrict__ cells,
+__global__ __launch_bounds__(64, FAST_WPS) void k_fast_cells(DGeom g, const OrbxCell *__restrict__ cells,
                                                    const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
                                                    int *__restrict__ cell_count, int rows, int lcap,
                                                    int cell_begin, int cell_end) {
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(64, 5) void k_fast_cells(DGeom g, const OrbxCell *_
     const int lcap_b = (2 * lcap + 3) & ~3;
     uint32_t *s_tile = (uint32_t *)fast_smem;
     uint8_t *s_score = fast_smem + rows * FAST_TP;
-    uint16_t *s_list = (uint16_t *)(fast_smem + 2 * rows * FAST_TP);          // [0,nA): compass@ini; (lcap-nB, lcap]: compass@min only
+    uint16_t *s_list = (uint16_t *)(fast_smem + 2 * rows * FAST_TP);          // [0,nB): compass@min (bit 15: also @ini); back of the corner array: compass@ini
     uint16_t *s_corn = (uint16_t *)(fast_smem + 2 * rows * FAST_TP + lcap_b);
     // blockIdx.x = frame: workgroups are dealt round-robin over the 8 XCDs in linear-id order, so with the frame as
     // the fastest grid dimension all cell groups of one frame share one XCD's L2 (overlapping tiles are fetched once)
@@ -280,36 +285,62 @@ __global__ __launch_bounds__(64, 5) void k_fast_cells(DGeom g, const OrbxCell *_
                 int e1 = max(min(max(b0, b8), max(b4, b12)) - v1, v1 - max(min(b0, b8), min(b4, b12)));
                 e0 = act0 ? e0 : -1;
                 e1 = act1 ? e1 : -1;
-                const uint16_t code0 = (uint16_t)((ly0 << 8) | lx), code1 = (uint16_t)((ly1 << 8) | lx);
-                {   // front of the list: passes at iniThFAST
-                    const unsigned long long m0 = __ballot(e0 > g.ini_th), m1 = __ballot(e1 > g.ini_th);
-                    if (e0 > g.ini_th) s_list[nA + orbx_wave_rank(m0)] = code0;
-                    nA += __popcll(m0);
-                    if (e1 > g.ini_th) s_list[nA + orbx_wave_rank(m1)] = code1;
-                    nA += __popcll(m1);
-                }
-                if (two_th) {   // back of the list: passes at minThFAST only
-                    const bool q0 = e0 > g.min_th && e0 <= g.ini_th, q1 = e1 > g.min_th && e1 <= g.ini_th;
-                    const unsigned long long m0 = __ballot(q0), m1 = __ballot(q1);
-                    if (q0) s_list[lcap - 1 - (nB + orbx_wave_rank(m0))] = code0;
-                    nB += __popcll(m0);
-                    if (q1) s_list[lcap - 1 - (nB + orbx_wave_rank(m1))] = code1;
-                    nB += __popcll(m1);
-                }
+                // ONE compaction per pixel slot: everything that passes at minThFAST goes to the front of the list,
+                // bit 15 of the code remembers whether it also passes at iniThFAST
+                const uint16_t code0 = (uint16_t)((ly0 << 8) | lx | ((e0 > g.ini_th) ? 0x8000 : 0));
+                const uint16_t code1 = (uint16_t)((ly1 << 8) | lx | ((e1 > g.ini_th) ? 0x8000 : 0));
+                const unsigned long long m0 = __ballot(e0 > g.min_th), m1 = __ballot(e1 > g.min_th);
+                if (e0 > g.min_th) s_list[nB + orbx_wave_rank(m0)] = code0;
+                nB += __popcll(m0);
+                if (e1 > g.min_th) s_list[nB + orbx_wave_rank(m1)] = code1;
+                nB += __popcll(m1);
             }
+        }
+        orbx_wave_sync();
+        // the (usually much shorter) iniThFAST list is filtered out of the front list into the BACK of the corner array
+        // (its front receives the corners of the pass).  If more than half of the cell passed at iniThFAST the two
+        // could collide: then pass 0 simply walks the front list and masks the lanes whose flag is clear.
+        bool a_in_back = false;
+        if (two_th) {
+            int na = 0;
+            for (int e0 = 0; e0 < nB; e0 += 64) {
+                const int e = e0 + lane;
+                na += __popcll(__ballot(e < nB && (s_list[e] & 0x8000) != 0));
+            }
+            a_in_back = 2 * na <= lcap;
+            if (a_in_back) {
+                for (int e0 = 0; e0 < nB; e0 += 64) {
+                    const int e = e0 + lane;
+                    const uint16_t code = e < nB ? s_list[e] : (uint16_t)0;
+                    const bool isA = (code & 0x8000) != 0;
+                    const unsigned long long m = __ballot(isA);
+                    if (isA) s_corn[lcap - 1 - (nA + orbx_wave_rank(m))] = (uint16_t)(code & 0x7fff);
+                    nA += __popcll(m);
+                }
+            } else {
+                nA = nB;   // walk the whole front list, flag-masked
+            }
+        } else {
+            nA = nB;       // one threshold: the front list IS the list of the only pass
         }
         orbx_wave_sync();
         uint2 *out = cand + (long long)f * g.cand_total + L.cand_begin + cur.slot_begin;
         int nsurv = 0;
         for (int pass = 0; pass < 2; ++pass) {
             const int th = pass == 0 ? g.ini_th : g.min_th;
-            const int nlist = pass == 0 ? nA : nA + nB;
+            const int nlist = pass == 0 ? nA : nB;
             // ---- phase 1b: full 16-ring test of the pre-selected pixels
             int ncorn = 0;
             for (int e0 = 0; e0 < nlist; e0 += 64) {
                 const int e = e0 + lane;
                 const bool valid = e < nlist;
-                const uint16_t code = !valid ? (uint16_t)((3 << 8) | 3) : e < nA ? s_list[e] : s_list[lcap - 1 - (e - nA)];
+                uint16_t code = (uint16_t)((3 << 8) | 3);
+                bool use = valid;
+                if (valid) {
+                    const uint16_t raw = (pass == 0 && a_in_back) ? s_corn[lcap - 1 - e] : s_list[e];
+                    if (pass == 0 && two_th && !a_in_back) use = (raw & 0x8000) != 0;   // flag-masked walk
+                    code = use ? (uint16_t)(raw & 0x7fff) : code;
+                }
                 const uint8_t *ptr = tile + (code >> 8) * FAST_TP + (code & 0xff);
                 const int v = ptr[0];
                 const int hi = v + th, lo = v - th;
@@ -320,7 +351,7 @@ __global__ __launch_bounds__(64, 5) void k_fast_cells(DGeom g, const OrbxCell *_
                     bright |= x > hi ? (1u << k) : 0u;   // v_cndmask(literal) + v_or: both full rate on gfx950
                     dark |= x < lo ? (1u << k) : 0u;     // (v_lshl_or_b32 is a half-rate VOP3)
                 }
-                const bool corner = (int)valid & ((int)orbx_arc9(bright) | (int)orbx_arc9(dark));
+                const bool corner = (int)use & ((int)orbx_arc9(bright) | (int)orbx_arc9(dark));
                 const unsigned long long m = __ballot(corner);
                 if (corner) s_corn[ncorn + orbx_wave_rank(m)] = code;
                 ncorn += __popcll(m);
