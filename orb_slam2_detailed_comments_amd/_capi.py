@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "liborbx.so")
+# ORBX_LIB: another build of the same library (kernel-variant sweeps in tools/); never a different implementation
+LIB_PATH = os.environ.get("ORBX_LIB") or os.path.join(HERE, "lib", "liborbx.so")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

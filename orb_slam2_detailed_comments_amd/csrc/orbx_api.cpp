@@ -39,6 +39,10 @@ struct orbx_handle {
     // geometry-dependent device state
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     OrbxCell *d_cells = nullptr;
+    OrbxFastGroup *d_groups = nullptr;
+    int fast_impl = 1;      // 1 = k_fast_rows (default), 0 = k_fast_cells (ORBX_FAST_IMPL=cells, kept for A/B runs)
+    int fast_stop = 0;      // ORBX_FAST_STOP: timing experiments only
+    int fast_lcap = 640;    // LDS work-list entries of k_fast_rows (ORBX_FAST_LCAP; tests shrink it to force the flush paths)
     OrbxTap *d_taps = nullptr;
     uint2 *d_cand = nullptr, *d_dense = nullptr;   // per-cell candidate slots / dense per-level key arrays
     int *d_cell_count = nullptr;
@@ -128,6 +132,7 @@ static void prof_drain(orbx_handle *h) {
 
 // ---------------------------------------------------------------- workspace
 static void free_geometry_buffers(orbx_handle *h) {
+    hipFree(h->d_groups); h->d_groups = nullptr;
     hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cells); hipFree(h->d_taps); hipFree(h->d_cand);
     hipFree(h->d_dense); hipFree(h->d_cell_count); h->d_dense = nullptr; h->d_cell_count = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_lvl_count); hipFree(h->d_status); hipFree(h->d_lvl_kp);
@@ -195,8 +200,14 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     HIPCHK(hipMalloc(&h->d_status, (size_t)B * sizeof(int)));
     HIPCHK(hipMalloc(&h->d_lvl_kp, (size_t)B * g.kp_total * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&h->d_lvl_angle, (size_t)B * g.kp_total * sizeof(float)));
-    if (!g.cells.empty())
+    HIPCHK(hipMalloc(&h->d_groups, std::max<size_t>(1, g.fast_groups.size()) * sizeof(OrbxFastGroup)));
+    if (!g.cells.empty()) {
         HIPCHK(hipMemcpy(h->d_cells, g.cells.data(), g.cells.size() * sizeof(OrbxCell), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_groups, g.fast_groups.data(), g.fast_groups.size() * sizeof(OrbxFastGroup), hipMemcpyHostToDevice));
+    }
+    if (const char *e = getenv("ORBX_FAST_IMPL")) h->fast_impl = strcmp(e, "cells") == 0 ? 0 : 1;
+    if (const char *e = getenv("ORBX_FAST_STOP")) h->fast_stop = atoi(e);
+    if (const char *e = getenv("ORBX_FAST_LCAP")) h->fast_lcap = std::max(64, atoi(e));
     if (!g.taps.empty())
         HIPCHK(hipMemcpy(h->d_taps, g.taps.data(), g.taps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(h->d_pyr, 0, (size_t)B * g.pyr_bytes));
@@ -323,7 +334,11 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
         orbx_launch_pyr_resize(s, g, B, l, h->d_taps, h->d_pyr);
     }
     { ProfScope ps(h, ORBX_K_FAST);
-      orbx_launch_fast(s, g, B, h->d_cells, h->d_pyr, h->d_cand, h->d_cell_count, h->max_cw, h->max_ch, 0, g.ncells); }
+      if (h->fast_impl == 1)
+          orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, (int)h->geom.fast_groups.size(), h->d_pyr, h->d_cand,
+                                h->d_cell_count, h->max_ch, h->fast_lcap, h->fast_stop);
+      else
+          orbx_launch_fast(s, g, B, h->d_cells, h->d_pyr, h->d_cand, h->d_cell_count, h->max_cw, h->max_ch, 0, g.ncells); }
     { ProfScope ps(h, ORBX_K_QUADTREE);
       orbx_launch_quadtree(s, g, B, h->d_cells, h->d_cand, h->d_cell_count, h->d_dense, h->d_cand_count, h->d_lvl_kp,
                            h->d_lvl_count, d_status, h->d_knode,

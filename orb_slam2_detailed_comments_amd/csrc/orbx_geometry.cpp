@@ -173,6 +173,20 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
             build_axis_taps(g.taps, L.ph, L.sh, S.ph, false);
         }
     }
+    // FAST wave groups: pair a cell with its right-hand neighbour when both interiors fit the 64 lanes of a wave
+    for (size_t i = 0; i < g.cells.size();) {
+        const OrbxCell &a = g.cells[i];
+        OrbxFastGroup grp;
+        grp.cell0 = (int32_t)i; grp.ncell = 1;
+        if (i + 1 < g.cells.size()) {
+            const OrbxCell &b = g.cells[i + 1];
+            const bool adjacent = b.level == a.level && b.y0 == a.y0 && b.ch == a.ch && b.x0 == a.x0 + a.cw - 6 &&
+                                  b.idx_in_level == a.idx_in_level + 1;
+            if (adjacent && (a.cw - 6) + (b.cw - 6) <= 64) grp.ncell = 2;
+        }
+        g.fast_groups.push_back(grp);
+        i += (size_t)grp.ncell;
+    }
     g.pyr_bytes = off;
     g.cand_total = cand_off;
     g.kp_total = kp_off;

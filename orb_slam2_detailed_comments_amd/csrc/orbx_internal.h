@@ -20,6 +20,13 @@ struct OrbxCell {
     int32_t slot_cap;        // slots reserved: strict 3x3 maxima leave at most one survivor per 2x2 block
 };
 
+// One wave of k_fast_rows: `ncell` (1 or 2) horizontally adjacent cells of one cell row whose interiors together span
+// at most 64 columns (one lane per interior column).
+struct OrbxFastGroup {
+    int32_t cell0;
+    int32_t ncell;
+};
+
 // resize tap for one padded destination coordinate (border folded in by reflect-101)
 struct OrbxTap {
     int16_t s0, s1;  // source index of the two taps (already clamped)
@@ -49,6 +56,7 @@ struct OrbxGeom {
     int width = 0, height = 0, nlevels = 0;
     OrbxLevelGeom lv[ORBX_MAX_LEVELS];
     std::vector<OrbxCell> cells;
+    std::vector<OrbxFastGroup> fast_groups;
     std::vector<OrbxTap> taps;
     int64_t pyr_bytes = 0;     // per frame
     int64_t cand_total = 0;    // per frame

@@ -183,6 +183,8 @@ __device__ __forceinline__ bool orbx_arc9(uint32_t mask16) {
 }
 
 // dynamic LDS: tile[rows*TP] | score[rows*TP] | list u16[lcap] (two-ended) | corn u16[lcap]; TP = tile pitch (%4 == 0)
+// ballot straight from the compare's lane mask (HIP's __ballot goes through an int and costs v_cndmask + v_cmp)
+__device__ __forceinline__ unsigned long long orbx_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int orbx_wave_rank(unsigned long long bal) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
 }
@@ -421,6 +423,315 @@ __global__ __launch_bounds__(64, FAST_WPS) void k_fast_cells(DGeom g, const Orbx
         }
         if (lane == 0) cell_count[(long long)f * g.ncells + cell0 + ci] = nsurv;
         orbx_wave_sync();   // the next cell overwrites tile / score / lists
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 (row-walk formulation): the same per-cell FAST-9/16 + score + NMS + threshold retry, organised so that the
+// dense part costs a dozen vector instructions per image ROW instead of per pixel pair:
+//   * one wave owns a GROUP of one or two horizontally adjacent cells (OrbxFastGroup); lane i is interior column i of
+//     the group and walks down the rows with the column's 7-row window in registers (one LDS byte per row), the two
+//     horizontal compass pixels come from LDS with immediate offsets -- no per-pixel address arithmetic;
+//   * the compass pre-test runs for ONE threshold (iniThFAST); the 4.6 % of cells that come out empty repeat the walk
+//     with minThFAST (reference :1519-1527), instead of every pixel paying for both thresholds;
+//   * 16-bit min/max (full rate on gfx950; the 32-bit forms are not) and a per-row ballot compaction into a bounded
+//     LDS list; the list is flushed through the full ring test + score whenever the next row might not fit, so the
+//     LDS footprint is independent of how many pixels pass;
+//   * NMS walks the corner list when every corner of the group fitted it, otherwise it rescans the score map.
+// Results (candidate records, per-cell counts) are identical to k_fast_cells.
+// ------------------------------------------------------------------------------------------------
+#ifndef FR_TP
+#define FR_TP 76        // LDS tile pitch: 64 interior columns + 6 ring + 3 alignment bytes -> 19 dwords (odd: rows spread over all banks)
+#endif
+#ifndef FR_WPS
+#define FR_WPS 4
+#endif
+typedef unsigned short fr_u16;
+typedef short fr_i16;
+typedef __attribute__((address_space(3))) uint16_t fr_lds_u16;
+__device__ __forceinline__ fr_u16 fr_max(fr_u16 a, fr_u16 b) { return a > b ? a : b; }
+__device__ __forceinline__ fr_u16 fr_min(fr_u16 a, fr_u16 b) { return a < b ? a : b; }
+__device__ __forceinline__ fr_i16 fr_smax(fr_i16 a, fr_i16 b) { return a > b ? a : b; }
+__device__ __forceinline__ fr_i16 fr_smin(fr_i16 a, fr_i16 b) { return a < b ? a : b; }
+
+struct FrCtx {
+    const uint8_t *tile;   // LDS tile, byte (0,0) = sub-mat origin of the group's first cell
+    uint8_t *score;        // LDS score map, same coordinates
+    uint16_t *list;        // LDS candidate / corner work list (lcap entries)
+    uint16_t *corn;        // LDS corner list of the whole group (lcap entries)
+    int lcap;
+    int lane;
+};
+
+// full 16-ring test of list[0..n) at threshold th, corners compacted IN PLACE to the front of the list, their scores
+// written to the score map; returns the number of corners
+__device__ __forceinline__ int fr_ring_and_score(const FrCtx &c, int n, int th, int dbg_stop) {
+    const int ro[16] = {3 * FR_TP,      3 * FR_TP + 1,  2 * FR_TP + 2,  FR_TP + 3, 3,  -FR_TP + 3,
+                        -2 * FR_TP + 2, -3 * FR_TP + 1, -3 * FR_TP,     -3 * FR_TP - 1, -2 * FR_TP - 2,
+                        -FR_TP - 3,     -3,             FR_TP - 3,      2 * FR_TP - 2,  3 * FR_TP - 1};
+    int ncorn = 0;
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + c.lane;
+        const bool valid = e < n;
+        const uint16_t code = valid ? c.list[e] : (uint16_t)(3 << 8);
+        const uint8_t *ptr = c.tile + (code >> 8) * FR_TP + 3 + (code & 0xff);
+        const int v = ptr[0];
+        const int hi = v + th, lo = v - th;
+        // ring masks by shift-in: mask = 2*mask + (compare) is one v_cmp + one v_addc per ring pixel and polarity
+        // (ring position k lands on bit 15-k; a circular run of 9 is a run of 9 in either direction)
+        uint32_t bright = 0, dark = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int x = ptr[ro[k]];
+            // (the compiler's own lowering is v_cmp -> SGPR, s_nop hazard padding, v_cndmask, v_or3, v_lshl)
+            asm("v_cmp_gt_i32 vcc, %2, %3\n\t"
+                "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                "v_cmp_lt_i32 vcc, %2, %4\n\t"
+                "v_addc_co_u32 %1, vcc, %1, %1, vcc"
+                : "+v"(bright), "+v"(dark)
+                : "v"(x), "v"(hi), "v"(lo)
+                : "vcc");
+        }
+        // (a pixel cannot have 9 brighter AND 9 darker ring pixels: the polarity of a corner is unique)
+        const bool cb = orbx_arc9(bright), cd = orbx_arc9(dark);
+        const bool corner = (int)valid & ((int)cb | (int)cd);
+        const unsigned long long m = orbx_ballot(corner);
+        // index <= e: this round's entries are already in registers.  Bit 15 = ring brighter than the centre.
+        if (corner) c.list[ncorn + orbx_wave_rank(m)] = (uint16_t)(code | (cb ? 0x8000u : 0u));
+        ncorn += __popcll(m);
+    }
+    orbx_wave_sync();
+    if (dbg_stop == 3) return ncorn;
+    // score = (largest t for which the corner test still passes) = max over the 16 arcs of the min over the arc of the
+    // signed difference, minus 1 (cv::cornerScore<16>).  The polarity that failed the test cannot exceed th, so only
+    // the corner's own polarity is evaluated: d = +-(v - ring), sliding 9-window minima by doubling (2, 4, 8, +1).
+    for (int e = c.lane; e < ncorn; e += 64) {
+        const uint16_t code = c.list[e];
+        const int off = ((code >> 8) & 0x7f) * FR_TP + 3 + (code & 0xff);
+        const uint8_t *ptr = c.tile + off;
+        // darker ring: complement both sides (255 - x) - (255 - v) = v - x, so one instruction stream serves both cases
+        const fr_u16 flip = (code & 0x8000u) != 0 ? (fr_u16)0 : (fr_u16)0xff;
+        const fr_i16 v = (fr_i16)((fr_u16)ptr[0] ^ flip);
+        fr_i16 d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = (fr_i16)((fr_i16)((fr_u16)ptr[ro[k]] ^ flip) - v);
+        fr_i16 a0 = (fr_i16)th;
+        fr_i16 m2[16], m4[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m2[k] = fr_smin(d[k], d[(k + 1) & 15]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m4[k] = fr_smin(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a0 = fr_smax(a0, fr_smin(fr_smin(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
+        c.score[off] = (uint8_t)(a0 - 1);
+    }
+    orbx_wave_sync();
+    return ncorn;
+}
+
+// strict 3x3 NMS of list[0..n) among the corners of the SAME cell, survivors straight to the cell's slot range
+struct FrCells {
+    int iw0;                        // interior columns of the first cell (64 when the group is a single cell)
+    int offx0, offx1, offy;         // j*wCell of the two cells, i*hCell
+    int ord0, ord1;                 // idx_in_level
+    int cap0, cap1;                 // slot_cap
+    uint2 *out0, *out1;             // slot ranges
+};
+__device__ __forceinline__ void fr_nms(const FrCtx &c, const FrCells &gc, const uint16_t *list, int n, int &ns0, int &ns1) {
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + c.lane;
+        const bool valid = e < n;
+        const uint16_t code = valid ? list[e] : (uint16_t)(3 << 8);
+        const int col = code & 0xff, ly = (code >> 8) & 0x7f;
+        const bool second = col >= gc.iw0;
+        const uint8_t *sp = c.score + ly * FR_TP + 3 + col;
+        const int sc = sp[0];
+        int l0 = sp[-FR_TP - 1], l1 = sp[-1], l2 = sp[FR_TP - 1];
+        int r0 = sp[-FR_TP + 1], r1 = sp[1], r2 = sp[FR_TP + 1];
+        const int u = sp[-FR_TP], dn = sp[FR_TP];
+        // the score map is shared by the two cells: the neighbours across the seam belong to the other cell's cv::FAST call
+        const bool seam_l = col == gc.iw0, seam_r = col == gc.iw0 - 1;
+        l0 = seam_l ? 0 : l0; l1 = seam_l ? 0 : l1; l2 = seam_l ? 0 : l2;
+        r0 = seam_r ? 0 : r0; r1 = seam_r ? 0 : r1; r2 = seam_r ? 0 : r2;
+        const bool keep = (int)valid & (int)(sc > l0) & (int)(sc > l1) & (int)(sc > l2) & (int)(sc > r0) & (int)(sc > r1) &
+                          (int)(sc > r2) & (int)(sc > u) & (int)(sc > dn);
+        const unsigned long long m = orbx_ballot(keep), msec = orbx_ballot(keep && second);
+        const unsigned long long mfirst = m & ~msec;
+        const int slot = second ? ns1 + orbx_wave_rank(msec) : ns0 + orbx_wave_rank(mfirst);
+        if (keep && slot < (second ? gc.cap1 : gc.cap0)) {
+            const int lx = 3 + col - (second ? gc.iw0 : 0);
+            uint2 o;
+            o.x = (uint32_t)(lx + (second ? gc.offx1 : gc.offx0)) | ((uint32_t)(ly + gc.offy) << 12) | ((uint32_t)sc << 24);
+            o.y = ((uint32_t)(second ? gc.ord1 : gc.ord0) << 12) | ((uint32_t)ly << 6) | (uint32_t)lx;   // emission order key
+            (second ? gc.out1 : gc.out0)[slot] = o;
+        }
+        ns0 += __popcll(mfirst);
+        ns1 += __popcll(msec);
+    }
+}
+
+__global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCell *__restrict__ cells,
+                                                          const OrbxFastGroup *__restrict__ groups,
+                                                          const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
+                                                          int *__restrict__ cell_count, int rows, int lcap, int dbg_stop) {
+    // dbg_stop (ORBX_FAST_STOP, timing experiments only; results are wrong unless 0): 1 = after staging, 2 = after the
+    // pre-test, 3 = after the ring test, 4 = before NMS
+    extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
+    uint32_t *s_tile = (uint32_t *)fast_smem;
+    uint8_t *s_score = fast_smem + rows * FR_TP;
+    uint16_t *s_list = (uint16_t *)(fast_smem + 2 * rows * FR_TP);   // lcap entries + one private dummy dword per lane
+    uint16_t *s_corn = s_list + lcap + 128;
+    const int lane = threadIdx.x;
+    const int f = blockIdx.x;   // frame fastest: all groups of one frame share one XCD's L2
+    const OrbxFastGroup grp = groups[blockIdx.y];
+    const OrbxCell c0 = cells[grp.cell0];
+    const OrbxCell c1 = cells[grp.cell0 + grp.ncell - 1];
+    const DLevel &L = g.lv[c0.level];
+    const int tw = c1.x0 + c1.cw - c0.x0, th_rows = c0.ch;
+    const int niw = tw - 6;                                   // interior columns of the group (<= 64)
+    const int iw0 = grp.ncell == 2 ? c0.cw - 6 : 64;
+    // ---- stage the tile: 3 rows x 21 dwords per step, every load in flight before the first LDS write
+    {
+        const int xa = c0.x0 & ~3, ndw = ((c0.x0 & 3) + tw + 3) >> 2;
+        const int rq = (lane * 49) >> 10, dq = lane - 21 * rq;
+        const bool ld = rq < 3 && dq < ndw;
+        const uint8_t *src = pyr + (long long)f * g.pyr_bytes + L.off + (long long)c0.y0 * L.pitch + xa + 4 * min(dq, ndw - 1);
+        uint32_t tv[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) tv[k] = *(const uint32_t *)(src + (long long)min(3 * k + rq, th_rows - 1) * L.pitch);
+#pragma unroll
+        for (int k = 0; k < 14; ++k) {
+            const int r = 3 * k + rq;
+            if (ld && r < th_rows) s_tile[r * (FR_TP / 4) + dq] = tv[k];
+        }
+        for (int r = 42 + rq; r < th_rows; r += 3)
+            if (ld) s_tile[r * (FR_TP / 4) + dq] = *(const uint32_t *)(src + (long long)r * L.pitch);
+        for (int i = lane; i < th_rows * (FR_TP / 4); i += 64) ((uint32_t *)s_score)[i] = 0;
+    }
+    FrCtx cx;
+    cx.tile = (const uint8_t *)s_tile + (c0.x0 & 3);
+    cx.score = s_score;
+    cx.list = s_list;
+    cx.corn = s_corn;
+    cx.lcap = lcap;
+    cx.lane = lane;
+    FrCells gc;
+    gc.iw0 = iw0;
+    gc.offx0 = c0.offx; gc.offx1 = c1.offx; gc.offy = c0.offy;
+    gc.ord0 = c0.idx_in_level; gc.ord1 = c1.idx_in_level;
+    gc.cap0 = c0.slot_cap; gc.cap1 = c1.slot_cap;
+    uint2 *lvl_out = cand + (long long)f * g.cand_total + L.cand_begin;
+    gc.out0 = lvl_out + c0.slot_begin; gc.out1 = lvl_out + c1.slot_begin;
+    orbx_wave_sync();
+    if (dbg_stop == 1) return;
+    const bool two_th = g.min_th != g.ini_th;
+    const bool colv = lane < niw;
+    const bool second = lane >= iw0;
+    const uint8_t *pc = cx.tile + 3 + (colv ? lane : 0);   // this lane's column, row 0
+    const int yend = th_rows - 3;
+    int ns0 = 0, ns1 = 0;
+    unsigned act = grp.ncell == 2 ? 3u : 1u;   // cells still to be detected in this pass
+    for (int pass = 0; pass < 2; ++pass) {
+        const int th = pass == 0 ? g.ini_th : g.min_th;
+        const bool lane_on = colv && ((act >> (second ? 1 : 0)) & 1u);
+        const unsigned long long lanes_on = orbx_ballot(lane_on);
+        int nctot = 0;
+        bool overflow = false;
+        int y = 3;
+        // lanes that are switched off (outside the group, or a cell that already has keypoints) carry a threshold no
+        // 8-bit difference reaches: the pre-test needs no separate lane mask
+        const fr_i16 thv = lane_on ? (fr_i16)th : (fr_i16)0x4000;
+        while (y < yend) {
+            // ---- compass pre-test, one row per step: a 9-arc of the 16-ring contains one pixel of every opposite
+            // pair, so max(min(max(r0,r8),max(r4,r12)) - v, v - max(min(r0,r8),min(r4,r12))) > th is necessary.
+            // The column window (rows y-3 .. y+3) rotates through seven registers: one new LDS byte per row.
+            // Scalar instructions issue at the same rate as vector ones, so the step is written to need only two
+            // (popcount + list cursor): no per-row exit test, no exec masking (lanes without a candidate write to a
+            // private dummy slot), the lane mask folded into the threshold.
+            const uint8_t *pr = pc + y * FR_TP;
+            fr_u16 w0 = pr[-3 * FR_TP], w1 = pr[-2 * FR_TP], w2 = pr[-FR_TP], w3 = pr[0], w4 = pr[FR_TP], w5 = pr[2 * FR_TP], w6;
+            // list cursor as an LDS byte ADDRESS (scalar): a lane's slot is one v_lshl_add away
+            const uint32_t list0 = (uint32_t)(uintptr_t)(fr_lds_u16 *)s_list;
+            uint32_t nb = list0;
+            uint32_t code = (uint32_t)((y << 8) | lane);
+            const uint32_t dummy = list0 + 2u * (uint32_t)lcap + 4u * (uint32_t)lane;
+#define FR_STEP(R8, C, R0)                                                                                              \
+            {                                                                                                           \
+                R0 = pr[3 * FR_TP];                                                                                     \
+                const fr_u16 r4 = pr[3], r12 = pr[-3];                                                                  \
+                const fr_u16 A = fr_min(fr_max(R0, R8), fr_max(r4, r12));                                               \
+                const fr_u16 Bm = fr_max(fr_min(R0, R8), fr_min(r4, r12));                                              \
+                const bool cnd = fr_smax((fr_i16)(A - C), (fr_i16)(C - Bm)) > thv;                                      \
+                const unsigned long long m = orbx_ballot(cnd);                                                          \
+                *(fr_lds_u16 *)(uintptr_t)(cnd ? nb + 2u * (uint32_t)orbx_wave_rank(m) : dummy) = (uint16_t)code;       \
+                nb += 2u * (uint32_t)__popcll(m);                                                                       \
+                pr += FR_TP;                                                                                            \
+                code += 0x100u;                                                                                         \
+            }
+            // full chunks of 7 rows while the list is guaranteed to take them
+            while (y + 7 <= yend && nb + 7u * 128u <= list0 + 2u * (uint32_t)lcap) {
+                FR_STEP(w0, w3, w6)
+                FR_STEP(w1, w4, w0)
+                FR_STEP(w2, w5, w1)
+                FR_STEP(w3, w6, w2)
+                FR_STEP(w4, w0, w3)
+                FR_STEP(w5, w1, w4)
+                FR_STEP(w6, w2, w5)
+                y += 7;
+            }
+            // remaining rows (and small work lists) one at a time, shifting the window
+            while (y < yend && nb + 128u <= list0 + 2u * (uint32_t)lcap) {
+                FR_STEP(w0, w3, w6)
+                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6;
+                ++y;
+            }
+#undef FR_STEP
+            const int n = (int)((nb - list0) >> 1);
+            orbx_wave_sync();
+            if (dbg_stop == 2) { if (n == 12345) cell_count[0] = n; continue; }
+            const int ncorn = fr_ring_and_score(cx, n, th, dbg_stop);
+            // keep the corners for the NMS walk while they fit
+            if (!overflow && nctot + ncorn <= lcap) {
+                for (int e = lane; e < ncorn; e += 64) s_corn[nctot + e] = s_list[e];
+                nctot += ncorn;
+            } else {
+                overflow = true;
+            }
+            orbx_wave_sync();
+        }
+        // ---- NMS
+        int a0 = 0, a1 = 0;
+        if (dbg_stop >= 2) { a0 = a1 = 1; } else
+        if (!overflow) {
+            fr_nms(cx, gc, s_corn, nctot, a0, a1);
+        } else {
+            for (int yy = 3; yy < yend;) {
+                int n = 0;
+                for (; yy < yend && n + 64 <= lcap; ++yy) {
+                    const bool cnd = lane_on && s_score[yy * FR_TP + 3 + lane] != 0;
+                    const unsigned long long m = orbx_ballot(cnd);
+                    if (cnd) s_list[n + orbx_wave_rank(m)] = (uint16_t)((yy << 8) | lane);
+                    n += __popcll(m);
+                }
+                orbx_wave_sync();
+                fr_nms(cx, gc, s_list, n, a0, a1);
+                orbx_wave_sync();
+            }
+        }
+        if (act & 1u) ns0 = a0;
+        if (act & 2u) ns1 = a1;
+        if (pass == 1 || !two_th) break;
+        // vKeysCell.empty() -> that cell alone repeats with minThFAST (:1519-1527)
+        act = (ns0 == 0 ? 1u : 0u) | ((grp.ncell == 2 && ns1 == 0) ? 2u : 0u);
+        if (act == 0) break;
+        orbx_wave_sync();
+        for (int i = lane; i < th_rows * (FR_TP / 4); i += 64) ((uint32_t *)s_score)[i] = 0;
+        orbx_wave_sync();
+    }
+    if (lane == 0) {
+        int *cc = cell_count + (long long)f * g.ncells + grp.cell0;
+        cc[0] = ns0;
+        if (grp.ncell == 2) cc[1] = ns1;
     }
 }
 
@@ -1318,6 +1629,13 @@ void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cell
     else
         hipLaunchKernelGGL(k_fast_cells<72>, grid, dim3(64), smem, s, g, cells, pyr, cand, cell_count, max_ch, lcap, cell_begin,
                            cell_end);
+}
+void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *groups,
+                           int ngroups, const uint8_t *pyr, uint2 *cand, int *cell_count, int max_ch, int lcap, int dbg_stop) {
+    if (ngroups <= 0) return;
+    lcap = (max(lcap, 64) + 1) & ~1;
+    const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256;
+    hipLaunchKernelGGL(k_fast_rows, dim3(B, ngroups), dim3(64), smem, s, g, cells, groups, pyr, cand, cell_count, max_ch, lcap, dbg_stop);
 }
 void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
                           const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,

@@ -339,3 +339,38 @@ def test_other_extractor_parameters(nf, sf, nl, ini, mn):
         out = orc.extract(frames[f], cap=ex.max_keypoints(640, 480))
         check_stages(ex, orc, f, nlevels=nl)
         assert_frame_equal(res[f], out, f"params {nf},{sf},{nl},{ini},{mn} frame {f}")
+
+
+@pytest.mark.parametrize("lcap", ["64", "128"])
+def test_fast_rows_small_work_list_flush_and_rescan_paths(lcap, monkeypatch):
+    """k_fast_rows with a tiny LDS work list: every group flushes several times and most groups overflow the corner
+    list (dense NMS rescan).  Candidates and the final result must not change."""
+    monkeypatch.setenv("ORBX_FAST_LCAP", lcap)
+    for (w, h, nf, sid) in [(640, 480, 1000, 21), (200, 150, 300, 22)]:
+        frames = synth.stream(w, h, 2, stream_id=sid)
+        ex = ORBextractor(nf, 1.2, 8, 20, 7, max_batch=2)
+        res = ex.extract_batch(frames)
+        orc = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+        for f in range(2):
+            out = orc.extract(frames[f], cap=ex.max_keypoints(w, h))
+            check_stages(ex, orc, f)
+            assert_frame_equal(res[f], out, f"lcap {lcap} {w}x{h} frame {f}")
+    for kind in ("checker", "square"):
+        img = synth.degenerate(kind, 320, 240)
+        k, d = ORBextractor(500)(img)
+        assert_frame_equal((k, d), oracle.OracleExtractor(500).extract(img), kind)
+    rng = np.random.Generator(np.random.PCG64(99))
+    img = rng.integers(0, 256, size=(240, 320), dtype=np.uint8)   # dense corners everywhere
+    k, d = ORBextractor(500)(img)
+    assert_frame_equal((k, d), oracle.OracleExtractor(500).extract(img), "noise")
+
+
+def test_fast_legacy_cell_kernel_still_matches(monkeypatch):
+    monkeypatch.setenv("ORBX_FAST_IMPL", "cells")
+    frames = synth.stream(640, 480, 1, stream_id=23)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    res = ex.extract_batch(frames)
+    orc = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    out = orc.extract(frames[0], cap=ex.max_keypoints(640, 480))
+    check_stages(ex, orc, 0)
+    assert_frame_equal(res[0], out, "legacy FAST kernel")
