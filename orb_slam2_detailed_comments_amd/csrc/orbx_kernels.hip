@@ -446,6 +446,9 @@ __global__ __launch_bounds__(64, FAST_WPS) void k_fast_cells(DGeom g, const Orbx
 #ifndef FR_WPS
 #define FR_WPS 4
 #endif
+#ifndef FR_GPW
+#define FR_GPW 2        // groups per wave
+#endif
 typedef unsigned short fr_u16;
 typedef short fr_i16;
 typedef __attribute__((address_space(3))) uint16_t fr_lds_u16;
@@ -573,7 +576,8 @@ __device__ __forceinline__ void fr_nms(const FrCtx &c, const FrCells &gc, const 
 __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCell *__restrict__ cells,
                                                           const OrbxFastGroup *__restrict__ groups,
                                                           const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
-                                                          int *__restrict__ cell_count, int rows, int lcap, int dbg_stop) {
+                                                          int *__restrict__ cell_count, int rows, int lcap, int ngroups,
+                                                          int dbg_stop) {
     // dbg_stop (ORBX_FAST_STOP, timing experiments only; results are wrong unless 0): 1 = after staging, 2 = after the
     // pre-test, 3 = after the ring test, 4 = before NMS
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
@@ -583,30 +587,52 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     uint16_t *s_corn = s_list + lcap + 128;
     const int lane = threadIdx.x;
     const int f = blockIdx.x;   // frame fastest: all groups of one frame share one XCD's L2
-    const OrbxFastGroup grp = groups[blockIdx.y];
-    const OrbxCell c0 = cells[grp.cell0];
-    const OrbxCell c1 = cells[grp.cell0 + grp.ncell - 1];
+    // FR_GPW groups per wave, one after the other: the next group's tile is fetched into registers while this one
+    // is processed, so the global-load latency is never waited for
+    const int g0 = blockIdx.y * FR_GPW;
+    const int ng = min(FR_GPW, ngroups - g0);
+    const int rq = (lane * 49) >> 10, dq = lane - 21 * rq;   // staging: 3 rows x 21 dwords per step
+    uint32_t tv[14];
+    OrbxFastGroup grp_n = groups[g0];
+    OrbxCell c0_n = cells[grp_n.cell0], c1_n = cells[grp_n.cell0 + grp_n.ncell - 1];
+#define FR_PREFETCH()                                                                                                     \
+    {                                                                                                                     \
+        const DLevel &Ln = g.lv[c0_n.level];                                                                             \
+        const int twn = c1_n.x0 + c1_n.cw - c0_n.x0;                                                                      \
+        const int ndwn = ((c0_n.x0 & 3) + twn + 3) >> 2;                                                                  \
+        const uint8_t *srcn = pyr + (long long)f * g.pyr_bytes + Ln.off + (long long)c0_n.y0 * Ln.pitch + (c0_n.x0 & ~3) + \
+                              4 * min(dq, ndwn - 1);                                                                      \
+        _Pragma("unroll") for (int k = 0; k < 14; ++k)                                                                    \
+            tv[k] = *(const uint32_t *)(srcn + (long long)min(3 * k + rq, (int)c0_n.ch - 1) * Ln.pitch);                  \
+    }
+    FR_PREFETCH()
+  for (int gi = 0; gi < ng; ++gi) {
+    const OrbxFastGroup grp = grp_n;
+    const OrbxCell c0 = c0_n, c1 = c1_n;
     const DLevel &L = g.lv[c0.level];
     const int tw = c1.x0 + c1.cw - c0.x0, th_rows = c0.ch;
     const int niw = tw - 6;                                   // interior columns of the group (<= 64)
     const int iw0 = grp.ncell == 2 ? c0.cw - 6 : 64;
-    // ---- stage the tile: 3 rows x 21 dwords per step, every load in flight before the first LDS write
+    // ---- stage the tile: prefetched registers -> LDS
     {
         const int xa = c0.x0 & ~3, ndw = ((c0.x0 & 3) + tw + 3) >> 2;
-        const int rq = (lane * 49) >> 10, dq = lane - 21 * rq;
         const bool ld = rq < 3 && dq < ndw;
-        const uint8_t *src = pyr + (long long)f * g.pyr_bytes + L.off + (long long)c0.y0 * L.pitch + xa + 4 * min(dq, ndw - 1);
-        uint32_t tv[14];
-#pragma unroll
-        for (int k = 0; k < 14; ++k) tv[k] = *(const uint32_t *)(src + (long long)min(3 * k + rq, th_rows - 1) * L.pitch);
 #pragma unroll
         for (int k = 0; k < 14; ++k) {
             const int r = 3 * k + rq;
             if (ld && r < th_rows) s_tile[r * (FR_TP / 4) + dq] = tv[k];
         }
-        for (int r = 42 + rq; r < th_rows; r += 3)
-            if (ld) s_tile[r * (FR_TP / 4) + dq] = *(const uint32_t *)(src + (long long)r * L.pitch);
+        if (th_rows > 42) {   // cells taller than the register window (tiny pyramid levels only)
+            const uint8_t *src = pyr + (long long)f * g.pyr_bytes + L.off + (long long)c0.y0 * L.pitch + xa + 4 * min(dq, ndw - 1);
+            for (int r = 42 + rq; r < th_rows; r += 3)
+                if (ld) s_tile[r * (FR_TP / 4) + dq] = *(const uint32_t *)(src + (long long)r * L.pitch);
+        }
         for (int i = lane; i < th_rows * (FR_TP / 4); i += 64) ((uint32_t *)s_score)[i] = 0;
+    }
+    if (gi + 1 < ng) {
+        grp_n = groups[g0 + gi + 1];
+        c0_n = cells[grp_n.cell0]; c1_n = cells[grp_n.cell0 + grp_n.ncell - 1];
+        FR_PREFETCH()
     }
     FrCtx cx;
     cx.tile = (const uint8_t *)s_tile + (c0.x0 & 3);
@@ -623,7 +649,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     uint2 *lvl_out = cand + (long long)f * g.cand_total + L.cand_begin;
     gc.out0 = lvl_out + c0.slot_begin; gc.out1 = lvl_out + c1.slot_begin;
     orbx_wave_sync();
-    if (dbg_stop == 1) return;
+    if (dbg_stop == 1) continue;
     const bool two_th = g.min_th != g.ini_th;
     const bool colv = lane < niw;
     const bool second = lane >= iw0;
@@ -655,17 +681,23 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
             uint32_t nb = list0;
             uint32_t code = (uint32_t)((y << 8) | lane);
             const uint32_t dummy = list0 + 2u * (uint32_t)lcap + 4u * (uint32_t)lane;
+            // software-pipelined: the three LDS bytes of row y+1 are requested before row y is evaluated (the list
+            // store could alias them as far as the compiler knows, so it would not hoist them itself); the row after
+            // the last one is read but never used (it is the first row of the score map)
+            uint32_t nx0 = pr[3 * FR_TP], nx4 = pr[3], nx12 = pr[-3];   // (32-bit carriers: no re-extension in the loop)
 #define FR_STEP(R8, C, R0)                                                                                              \
             {                                                                                                           \
-                R0 = pr[3 * FR_TP];                                                                                     \
-                const fr_u16 r4 = pr[3], r12 = pr[-3];                                                                  \
+                R0 = (fr_u16)nx0;                                                                                       \
+                const fr_u16 r4 = (fr_u16)nx4, r12 = (fr_u16)nx12;                                                      \
+                pr += FR_TP;                                                                                            \
+                nx0 = pr[3 * FR_TP]; nx4 = pr[3]; nx12 = pr[-3];                                                        \
+                asm("" : "+v"(nx0), "+v"(nx4), "+v"(nx12));   /* keeps the carriers 32-bit (no v_and / SDWA re-extension) */ \
                 const fr_u16 A = fr_min(fr_max(R0, R8), fr_max(r4, r12));                                               \
                 const fr_u16 Bm = fr_max(fr_min(R0, R8), fr_min(r4, r12));                                              \
                 const bool cnd = fr_smax((fr_i16)(A - C), (fr_i16)(C - Bm)) > thv;                                      \
                 const unsigned long long m = orbx_ballot(cnd);                                                          \
                 *(fr_lds_u16 *)(uintptr_t)(cnd ? nb + 2u * (uint32_t)orbx_wave_rank(m) : dummy) = (uint16_t)code;       \
                 nb += 2u * (uint32_t)__popcll(m);                                                                       \
-                pr += FR_TP;                                                                                            \
                 code += 0x100u;                                                                                         \
             }
             // full chunks of 7 rows while the list is guaranteed to take them
@@ -733,6 +765,9 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         cc[0] = ns0;
         if (grp.ncell == 2) cc[1] = ns1;
     }
+    orbx_wave_sync();   // the next group overwrites tile / score / lists
+  }
+#undef FR_PREFETCH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1635,7 +1670,8 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
     if (ngroups <= 0) return;
     lcap = (max(lcap, 64) + 1) & ~1;
     const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256;
-    hipLaunchKernelGGL(k_fast_rows, dim3(B, ngroups), dim3(64), smem, s, g, cells, groups, pyr, cand, cell_count, max_ch, lcap, dbg_stop);
+    hipLaunchKernelGGL(k_fast_rows, dim3(B, (ngroups + FR_GPW - 1) / FR_GPW), dim3(64), smem, s, g, cells, groups, pyr, cand,
+                       cell_count, max_ch, lcap, ngroups, dbg_stop);
 }
 void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
                           const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,
