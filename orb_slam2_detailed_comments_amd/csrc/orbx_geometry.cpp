@@ -165,12 +165,24 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
         g.max_cand_cap = std::max(g.max_cand_cap, L.cand_cap);
         // resize taps (level > 0: source is the PADDED previous level)
         L.tapx_begin = L.tapy_begin = 0;
+        L.narrow_taps = false;
         if (l > 0) {
             const OrbxLevelGeom &S = g.lv[l - 1];
             L.tapx_begin = (int)g.taps.size();
             build_axis_taps(g.taps, L.pw, L.sw, S.pw, true);
             L.tapy_begin = (int)g.taps.size();
             build_axis_taps(g.taps, L.ph, L.sh, S.ph, false);
+            L.narrow_taps = true;
+            for (int X = 0; X < L.pw; X += 4) {
+                int lo = 0x7fff, hi = 0;
+                for (int i = 0; i < 4; ++i) {
+                    const OrbxTap &t = g.taps[L.tapx_begin + std::min(X + i, L.pw - 1)];
+                    lo = std::min<int>(lo, t.s0); hi = std::max<int>(hi, t.s0);
+                    // the kernel reads the second tap as "the next byte": true unless clamped, where its weight is 0
+                    if (t.s1 != t.s0 + 1 && t.a1 != 0) L.narrow_taps = false;
+                }
+                if (hi + 2 - lo > 8) L.narrow_taps = false;
+            }
         }
     }
     // FAST wave groups: pair a cell with its right-hand neighbour when both interiors fit the 64 lanes of a wave

@@ -48,6 +48,7 @@ struct OrbxLevelGeom {
     int cand_cap;        // candidate slots
     int64_t cand_begin;  // offset inside the per-frame candidate table
     int tapx_begin, tapy_begin;  // offsets into the tap table (level > 0)
+    bool narrow_taps;    // every aligned group of 4 destination columns reads <= 8 consecutive source bytes (k_pyr_resize_rows)
     float scale;         // mvScaleFactor[level]
     float size;          // (float)(int)(31 * scale)
 };

@@ -96,6 +96,11 @@ __global__ __launch_bounds__(256) void k_pyr_l0_color(DGeom g, const uint8_t *__
 // in one pass: the border is produced by evaluating the bilinear formula at the reflected coordinate
 // (taps precomputed per padded coordinate on the host).  (reference :2119-2143)
 // ------------------------------------------------------------------------------------------------
+typedef uint2 __attribute__((aligned(1))) orbx_uint2_u;   // 8 bytes at any byte address (global memory takes unaligned accesses)
+typedef unsigned short orbx_v2u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t orbx_udot2(uint32_t a, uint32_t b) {   // a.lo * b.lo + a.hi * b.hi, exact
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(orbx_v2u16, a), __builtin_bit_cast(orbx_v2u16, b), 0u, false);
+}
 #define RS_ROWS 2   // destination rows per thread: the horizontal taps and byte selectors are shared, 12 loads in flight
 __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const OrbxTap *__restrict__ taps,
                                                     uint8_t *__restrict__ pyr) {
@@ -119,9 +124,45 @@ __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const Or
         smin = min(smin, (int)tx[i].s0);
         smax = max(smax, (int)tx[i].s0);
     }
+    OrbxTap ty[RS_ROWS];
+    if (smax + 2 - smin <= 8) {
+        // ---- narrow footprint (every usual scale factor): the <= 8 source bytes a thread needs per source row come
+        // with ONE unaligned 8-byte load; v_perm_b32 puts the two taps of a destination pixel into the 16-bit halves
+        // of a register and v_dot2_u32_u16 against the packed weights (a0 | a1 << 16 = the second dword of the tap
+        // record) is the horizontal pass: two instructions per pixel and source row, no selects, no multiplies.
+        uint32_t sel[4], wgt[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t d = (uint32_t)(tx[i].s0 - smin);              // 0..6; second tap = next byte (weight 0 when clamped)
+            sel[i] = d | (0x0cu << 8) | ((d + 1u) << 16) | (0x0cu << 24);   // 0x0c selects the constant 0x00
+            wgt[i] = (uint32_t)(uint16_t)tx[i].a0 | ((uint32_t)(uint16_t)tx[i].a1 << 16);
+        }
+        uint2 u[RS_ROWS], w[RS_ROWS];
+#pragma unroll
+        for (int r = 0; r < RS_ROWS; ++r) {
+            ty[r] = taps[L.tapy + min(Y0 + r, L.ph - 1)];
+            u[r] = *(const orbx_uint2_u *)(base + S.off + (long long)ty[r].s0 * S.pitch + smin);
+            w[r] = *(const orbx_uint2_u *)(base + S.off + (long long)ty[r].s1 * S.pitch + smin);
+        }
+#pragma unroll
+        for (int r = 0; r < RS_ROWS; ++r) {
+            const int Y = Y0 + r;
+            if (Y >= L.ph) break;
+            const uint32_t b0 = (uint32_t)ty[r].a0 & 0xfffu, b1 = (uint32_t)ty[r].a1 & 0xfffu;
+            uint32_t v = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t T0 = orbx_udot2(__builtin_amdgcn_perm(u[r].y, u[r].x, sel[i]), wgt[i]);
+                const uint32_t T1 = orbx_udot2(__builtin_amdgcn_perm(w[r].y, w[r].x, sel[i]), wgt[i]);
+                const uint32_t p = ((__umul24(b0, T0 >> 4) >> 16) + (__umul24(b1, T1 >> 4) >> 16) + 2u) >> 2;   // <= 255
+                v |= p << (8 * i);
+            }
+            *(uint32_t *)(base + L.off + (long long)Y * L.pitch + X) = v;
+        }
+        return;
+    }
     const int xb = smin & ~3;
     const bool windowed = smax + 1 - xb < 12;
-    OrbxTap ty[RS_ROWS];
     uint32_t u[RS_ROWS][3], w[RS_ROWS][3];
 #pragma unroll
     for (int r = 0; r < RS_ROWS; ++r) {
@@ -164,6 +205,140 @@ __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const Or
             }
         }
         *(uint32_t *)(base + L.off + (long long)Y * L.pitch + X) = v;
+    }
+}
+
+// Row-loop form of the narrow-footprint path (the one every usual geometry takes; the host checks the tap table and
+// launches k_pyr_resize above otherwise).  k_pyr_resize is latency-bound: tap records -> source loads -> store is a
+// chain of two dependent global loads per 512 bytes written, and its 256-pixel column strips leave up to 40 % of the
+// lanes of a level idle.  Here
+//   * the (row pair, dword column) items of RS2_RB row pairs are laid out linearly over the lanes, so every lane has
+//     work whatever the level width;
+//   * a lane keeps its horizontal selectors / weights in registers and walks `nit` blocks of rows; the vertical taps
+//     and source rows of step k+1 are requested before step k is evaluated: nothing in the loop waits on a table;
+//   * `nit` is chosen per level on the host so that small levels still fill the chip with waves.
+#define RS2_RB 4   // row pairs per block of rows
+__global__ __launch_bounds__(256) void k_pyr_resize_flat(DGeom g, int level, const OrbxTap *__restrict__ taps,
+                                                         uint8_t *__restrict__ pyr, int nit) {
+    const DLevel &L = g.lv[level];
+    const DLevel &S = g.lv[level - 1];
+    const int ndw = (L.pw + 3) >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= RS2_RB * ndw) return;
+    const int rp = q / ndw, X = 4 * (q - rp * ndw);
+    const int f = blockIdx.z;
+    const int y_first = blockIdx.y * (nit * 2 * RS2_RB) + 2 * rp;
+    if (y_first >= L.ph) return;
+    uint8_t *base = pyr + (long long)f * g.pyr_bytes;
+    const uint8_t *src = base + S.off;
+    uint8_t *dst = base + L.off + X;
+    uint32_t sel[4], wgt[4];
+    int smin = 0x7fff;
+    {
+        const uint2 *tq = (const uint2 *)taps + L.tapx;
+        uint2 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = tq[min(X + i, L.pw - 1)];   // .x = s0 | s1 << 16, .y = a0 | a1 << 16
+#pragma unroll
+        for (int i = 0; i < 4; ++i) smin = min(smin, (int)(t[i].x & 0xffffu));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t d = (t[i].x & 0xffffu) - (uint32_t)smin;          // 0..6 (checked on the host)
+            sel[i] = d | (0x0cu << 8) | ((d + 1u) << 16) | (0x0cu << 24);
+            wgt[i] = t[i].y;
+        }
+    }
+    src += smin;
+    const uint2 *ty = (const uint2 *)taps + L.tapy;
+    const int ylast = L.ph - 1;
+    // prologue: taps and source rows of the first step
+    uint2 ta = ty[y_first], tb = ty[min(y_first + 1, ylast)];
+    uint2 ua = *(const orbx_uint2_u *)(src + (long long)(ta.x & 0xffffu) * S.pitch), wa = *(const orbx_uint2_u *)(src + (long long)(ta.x >> 16) * S.pitch);
+    uint2 ub = *(const orbx_uint2_u *)(src + (long long)(tb.x & 0xffffu) * S.pitch), wb = *(const orbx_uint2_u *)(src + (long long)(tb.x >> 16) * S.pitch);
+    int Y = y_first;
+    for (int it = 0; it < nit && Y < L.ph; ++it, Y += 2 * RS2_RB) {
+        const uint2 ca = ta, cb = tb, cua = ua, cwa = wa, cub = ub, cwb = wb;
+        {   // next step's rows, in flight while this step is evaluated (clamped past the end: loaded, never used)
+            const int Yn = min(Y + 2 * RS2_RB, ylast);
+            ta = ty[Yn]; tb = ty[min(Yn + 1, ylast)];
+            ua = *(const orbx_uint2_u *)(src + (long long)(ta.x & 0xffffu) * S.pitch); wa = *(const orbx_uint2_u *)(src + (long long)(ta.x >> 16) * S.pitch);
+            ub = *(const orbx_uint2_u *)(src + (long long)(tb.x & 0xffffu) * S.pitch); wb = *(const orbx_uint2_u *)(src + (long long)(tb.x >> 16) * S.pitch);
+        }
+        uint32_t va = 0, vb = 0;
+        const uint32_t a0 = ca.y & 0xfffu, a1 = (ca.y >> 16) & 0xfffu, b0 = cb.y & 0xfffu, b1 = (cb.y >> 16) & 0xfffu;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t T0 = orbx_udot2(__builtin_amdgcn_perm(cua.y, cua.x, sel[i]), wgt[i]);
+            const uint32_t T1 = orbx_udot2(__builtin_amdgcn_perm(cwa.y, cwa.x, sel[i]), wgt[i]);
+            const uint32_t T2 = orbx_udot2(__builtin_amdgcn_perm(cub.y, cub.x, sel[i]), wgt[i]);
+            const uint32_t T3 = orbx_udot2(__builtin_amdgcn_perm(cwb.y, cwb.x, sel[i]), wgt[i]);
+            va |= (((__umul24(a0, T0 >> 4) >> 16) + (__umul24(a1, T1 >> 4) >> 16) + 2u) >> 2) << (8 * i);
+            vb |= (((__umul24(b0, T2 >> 4) >> 16) + (__umul24(b1, T3 >> 4) >> 16) + 2u) >> 2) << (8 * i);
+        }
+        *(uint32_t *)(dst + (long long)Y * L.pitch) = va;
+        if (Y + 1 < L.ph) *(uint32_t *)(dst + (long long)(Y + 1) * L.pitch) = vb;
+    }
+}
+
+// Strip form: a wave owns a 256-pixel column strip (64 lanes x 4 px) and walks `rpw` destination rows, two per step;
+// the rows are wave-uniform, so the vertical taps are scalar loads.
+__global__ __launch_bounds__(256) void k_pyr_resize_rows(DGeom g, int level, const OrbxTap *__restrict__ taps,
+                                                         uint8_t *__restrict__ pyr, int rpw) {
+    const DLevel &L = g.lv[level];
+    const DLevel &S = g.lv[level - 1];
+    const int lane = threadIdx.x;
+    const int X = (blockIdx.x * 64 + lane) * 4;
+    const int f = blockIdx.z;
+    const int y_begin = __builtin_amdgcn_readfirstlane((blockIdx.y * 4 + threadIdx.y) * rpw);
+    if (y_begin >= L.ph) return;
+    const int y_end = min(y_begin + rpw, L.ph);
+    const bool on = X < L.pw;
+    uint8_t *base = pyr + (long long)f * g.pyr_bytes;
+    const uint8_t *src = base + S.off;
+    uint8_t *dst = base + L.off + X;
+    uint32_t sel[4], wgt[4];
+    int smin = 0x7fff;
+    {
+        const uint2 *tq = (const uint2 *)taps + L.tapx;
+        uint2 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = tq[min(X + i, L.pw - 1)];   // .x = s0 | s1 << 16, .y = a0 | a1 << 16
+#pragma unroll
+        for (int i = 0; i < 4; ++i) smin = min(smin, (int)(t[i].x & 0xffffu));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t d = (t[i].x & 0xffffu) - (uint32_t)smin;          // 0..6 (checked on the host)
+            sel[i] = d | (0x0cu << 8) | ((d + 1u) << 16) | (0x0cu << 24);
+            wgt[i] = t[i].y;
+        }
+    }
+    src += smin;
+    const uint2 *ty = (const uint2 *)taps + L.tapy;
+    uint2 ta = ty[y_begin], tb = ty[min(y_begin + 1, L.ph - 1)];
+    uint2 ua = *(const orbx_uint2_u *)(src + (long long)(ta.x & 0xffffu) * S.pitch), wa = *(const orbx_uint2_u *)(src + (long long)(ta.x >> 16) * S.pitch);
+    uint2 ub = *(const orbx_uint2_u *)(src + (long long)(tb.x & 0xffffu) * S.pitch), wb = *(const orbx_uint2_u *)(src + (long long)(tb.x >> 16) * S.pitch);
+    for (int Y = y_begin; Y < y_end; Y += 2) {
+        const uint2 ca = ta, cb = tb, cua = ua, cwa = wa, cub = ub, cwb = wb;
+        if (Y + 2 < y_end) {   // next step's rows, in flight while this step is evaluated
+            ta = ty[Y + 2]; tb = ty[min(Y + 3, L.ph - 1)];
+            ua = *(const orbx_uint2_u *)(src + (long long)(ta.x & 0xffffu) * S.pitch); wa = *(const orbx_uint2_u *)(src + (long long)(ta.x >> 16) * S.pitch);
+            ub = *(const orbx_uint2_u *)(src + (long long)(tb.x & 0xffffu) * S.pitch); wb = *(const orbx_uint2_u *)(src + (long long)(tb.x >> 16) * S.pitch);
+        }
+        uint32_t va = 0, vb = 0;
+        const uint32_t a0 = ca.y & 0xfffu, a1 = (ca.y >> 16) & 0xfffu, b0 = cb.y & 0xfffu, b1 = (cb.y >> 16) & 0xfffu;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t T0 = orbx_udot2(__builtin_amdgcn_perm(cua.y, cua.x, sel[i]), wgt[i]);
+            const uint32_t T1 = orbx_udot2(__builtin_amdgcn_perm(cwa.y, cwa.x, sel[i]), wgt[i]);
+            const uint32_t T2 = orbx_udot2(__builtin_amdgcn_perm(cub.y, cub.x, sel[i]), wgt[i]);
+            const uint32_t T3 = orbx_udot2(__builtin_amdgcn_perm(cwb.y, cwb.x, sel[i]), wgt[i]);
+            va |= (((__umul24(a0, T0 >> 4) >> 16) + (__umul24(a1, T1 >> 4) >> 16) + 2u) >> 2) << (8 * i);
+            vb |= (((__umul24(b0, T2 >> 4) >> 16) + (__umul24(b1, T3 >> 4) >> 16) + 2u) >> 2) << (8 * i);
+        }
+        if (on) {
+            *(uint32_t *)(dst + (long long)Y * L.pitch) = va;
+            if (Y + 1 < y_end) *(uint32_t *)(dst + (long long)(Y + 1) * L.pitch) = vb;
+        }
     }
 }
 
@@ -1645,8 +1820,29 @@ void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_
     dim3 grid((L.pw + 255) / 256, (L.ph + 3) / 4, B);
     hipLaunchKernelGGL(k_pyr_l0_color, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, nch, r_off, b_off);
 }
-void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr) {
+void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr, bool narrow) {
     const DLevel &L = g.lv[level];
+    if (narrow) {
+        static int impl = -1, par = 0;
+        if (impl < 0) {   // ORBX_RESIZE_IMPL=flat[:nit] / rows[:rpw] (A/B runs); default rows:16
+            const char *e = getenv("ORBX_RESIZE_IMPL");
+            impl = (e && strncmp(e, "flat", 4) == 0) ? 1 : 0;
+            const char *c = e ? strchr(e, ':') : nullptr;
+            par = c ? atoi(c + 1) : 0;
+        }
+        if (impl == 1) {
+            const int ndw = (L.pw + 3) / 4, bx = (RS2_RB * ndw + 255) / 256;
+            const int row_blocks = (L.ph + 2 * RS2_RB - 1) / (2 * RS2_RB);
+            const int nit = par > 0 ? par : 8;
+            dim3 grid(bx, (row_blocks + nit - 1) / nit, B);
+            hipLaunchKernelGGL(k_pyr_resize_flat, grid, dim3(256), 0, s, g, level, taps, pyr, nit);
+        } else {
+            const int rpw = par > 0 ? par : 16;
+            dim3 grid((L.pw + 255) / 256, (L.ph + 4 * rpw - 1) / (4 * rpw), B);
+            hipLaunchKernelGGL(k_pyr_resize_rows, grid, dim3(64, 4), 0, s, g, level, taps, pyr, rpw);
+        }
+        return;
+    }
     dim3 grid((L.pw + 255) / 256, (L.ph + 4 * RS_ROWS - 1) / (4 * RS_ROWS), B);
     hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, g, level, taps, pyr);
 }
