@@ -46,10 +46,26 @@ __device__ __forceinline__ int orbx_reflect101(int i, int n) {
     return i;
 }
 
+// cross-lane moves through DPP (a VALU modifier) instead of __shfl (ds_bpermute occupies the LDS pipe for ~10 ns per
+// wave on gfx950 against ~1.8 ns for a DPP move)
+#define ORBX_DPP_ROW_SHR(n) (0x110 + (n))
+#define ORBX_DPP_WAVE_SHL1 0x130   // lane i <- lane i + 1
+#define ORBX_DPP_ROW_BCAST15 0x142
+#define ORBX_DPP_ROW_BCAST31 0x143
+__device__ __forceinline__ uint32_t orbx_lane_above(uint32_t v) {   // value of lane + 1 (lane 63 gets 0)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ORBX_DPP_WAVE_SHL1, 0xf, 0xf, true);
+}
+// sum over the 64 lanes, returned wave-uniform: shift-adds inside each row of 16, then row broadcasts (the canonical
+// GCN reduction), result read from lane 63
 __device__ __forceinline__ int orbx_wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    int t = v + __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_SHR(1), 0xf, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_SHR(2), 0xf, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_SHR(3), 0xf, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, t, ORBX_DPP_ROW_SHR(4), 0xf, 0xe, true);
+    t += __builtin_amdgcn_update_dpp(0, t, ORBX_DPP_ROW_SHR(8), 0xf, 0xc, true);
+    t += __builtin_amdgcn_update_dpp(0, t, ORBX_DPP_ROW_BCAST15, 0xa, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, t, ORBX_DPP_ROW_BCAST31, 0xc, 0xf, true);
+    return __builtin_amdgcn_readlane(t, 63);
 }
 
 // cv::fastAtan2 (degrees), OpenCV 3.2 atanImpl<float>; no contraction (file is built -ffp-contract=off)

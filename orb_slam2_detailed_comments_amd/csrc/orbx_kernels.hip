@@ -1398,186 +1398,221 @@ __constant__ int4 c_pattern_lane[64];
 #define DS_W (2 * DS_R + 1)     // 43
 #define DS_PP 44                // LDS patch pitch in bytes (11 dwords; rows start dword-aligned in LDS)
 #define DS_HC 40                // row-pass outputs per row (37 needed, computed in groups of 4)
-__global__ __launch_bounds__(256) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
+// a real call: inlined into the keypoint loop, the dozen double-precision constants of the polynomial are hoisted
+// out of the loop and pinned in 20+ VGPRs for the whole kernel
+__device__ __attribute__((noinline)) OrbxSinCos orbx_sincosf_call(float y) { return orbx_sincosf_pinned(y); }
+#ifndef DS_WPS
+#define DS_WPS 7   // waves per SIMD the register allocation must allow (LDS admits 7 blocks of 4 waves per CU)
+#endif
+// Keypoints per wave, one after the other with the next patch prefetched into registers.  Measured on MI355X (256 frames):
+// 1 -> 375 us, 2 / 4 / 8 at 4-5 waves per SIMD -> 430-440 us: every phase of this kernel is a dependent chain of LDS
+// round trips, so what hides latency is the number of resident waves, and the registers of the prefetch cost more
+// occupancy than the prefetch recovers.  The loop stays (DS_KPW is a build knob), the default is one keypoint per wave.
+#ifndef DS_KPW
+#define DS_KPW 1
+#endif
+__global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
                                                   const uint32_t *__restrict__ lvl_kp,
                                                   const int *__restrict__ lvl_count,
                                                   float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int *__restrict__ counts,
-                                                  int *__restrict__ status, int cap) {
+                                                  int *__restrict__ status, int cap, int dbg_stop) {
+    // dbg_stop (ORBX_DESC_STOP, timing experiments only): 1 = after staging, 2 = after orientation, 3 = after the row pass
     __shared__ uint32_t s_patch[4][DS_W * DS_PP / 4 + 4];
     __shared__ __attribute__((aligned(8))) uint16_t s_h[4][DS_W * DS_HC];
-    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
-    const int slot = blockIdx.y * 4 + wv_id;
+    const int lane0 = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     const int f = blockIdx.x;   // frame fastest: one frame's patches stay in one XCD's L2
-    if (slot >= g.kp_total) return;
-    int level, idx;
-    orbx_slot_to_level(g, slot, level, idx);
-    // independent loads first: position, this lane's 8 pattern points, the per-level counts
-    const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];
-    const int4 pat = c_pattern_lane[lane];
+    // A wave takes DS_KPW consecutive OUTPUT indices (level-major order of operator(), :2066-2082): the staging of a
+    // patch is a chain of dependent global loads (position -> rows), so the rows of keypoint k+1 are requested
+    // before keypoint k is evaluated and land in registers while the wave computes.
+    const int o0 = (blockIdx.y * 4 + wv_id) * DS_KPW;
     const int *lc = lvl_count + f * g.nlevels;
-    int before = 0, total = 0, mine = 0;
+    int total = 0;
+    // this lane's keypoint (lanes 0 .. DS_KPW-1): level / slot from the per-level counts
+    const int omine = o0 + lane0;
+    int lev_l = 0, slot_l = omine;
 #pragma unroll
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         if (l < g.nlevels) {
-            const int c = lc[l];
-            if (l < level) before += c;
-            if (l == level) mine = c;
-            total += c;
+            if (omine >= total) { lev_l = l; slot_l = g.lv[l].kp_begin + (omine - total); }
+            total += lc[l];
         }
     }
-    if (slot == 0 && lane == 0) {
+    if (blockIdx.y == 0 && wv_id == 0 && lane0 == 0) {
         counts[f] = min(total, cap);
         if (total > cap) atomicMax(&status[f], (int)ORBX_CAPACITY);
     }
-    if (idx >= mine) return;
-    const int oi = before + idx;
-    if (oi >= cap) return;
-    const DLevel &L = g.lv[level];
-    const int x = (int)(pos & 0xfff) + (ORBX_EDGE - 3), y = (int)((pos >> 12) & 0xfff) + (ORBX_EDGE - 3);
-    const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;
-    // ---- stage the 43x43 patch (rows y-21.., columns x-21..): 11 dwords per row, loaded from the (generally
-    // unaligned) byte address so that every LDS row starts dword-aligned
+    const int nvalid = min(total, cap);
+    if (o0 >= nvalid) return;
+    const int nk = min(DS_KPW, nvalid - o0);
+    const uint32_t pos_l = lvl_kp[(long long)f * g.kp_total + min(slot_l, g.kp_total - 1)];
     uint32_t *patch = s_patch[wv_id];
     uint16_t *hrow = s_h[wv_id];
-    const int px0 = x - DS_R, py0 = y - DS_R;
-    const int xa = px0 & ~3;
-    const uint32_t shift = (uint32_t)(px0 & 3);
+    const int dq = lane0 % 12, rq = lane0 / 12;   // staging: 5 rows x 12 aligned dwords per step
+    uint32_t tv[9];
+    // geometry of keypoint k (wave-uniform) and the request of its rows
+#define DS_GEOM(K)                                                                                                        \
+    const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)pos_l, K);                                               \
+    const int level = __builtin_amdgcn_readlane(lev_l, K);                                                                \
+    const DLevel &L = g.lv[level];                                                                                        \
+    const int x = (int)(pos & 0xfff) + (ORBX_EDGE - 3), y = (int)((pos >> 12) & 0xfff) + (ORBX_EDGE - 3);                 \
+    const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;                                                        \
+    const int px0 = x - DS_R, py0 = y - DS_R;                                                                             \
+    const int xa = px0 & ~3;                                                                                              \
     const bool interior = px0 >= 0 && py0 >= 0 && xa + 48 <= L.pitch && x + DS_R < L.pw && y + DS_R < L.ph;
-    if (interior) {
-        // 12 ALIGNED dwords cover the 44 bytes of a patch row; dword d of the LDS row = funnel shift of aligned
-        // dwords d, d+1 (the neighbour lane's register, fetched with one cross-lane read).  5 rows x 12 lanes per step.
-        const int dq = lane % 12, rq = lane / 12;
-        uint32_t tv[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int r = min(5 * k + rq, DS_W - 1);
-            tv[k] = lane < 60 ? *(const uint32_t *)(img + (long long)(py0 + r) * L.pitch + xa + 4 * dq) : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const uint32_t nxt = (uint32_t)__shfl_down((int)tv[k], 1, 64);
-            const int r = 5 * k + rq;
-            if (lane < 60 && dq < 11 && r < DS_W) patch[r * (DS_PP / 4) + dq] = __builtin_amdgcn_alignbyte(nxt, tv[k], shift);
-        }
-    } else {
-        // image edge: reflect-101 of the padded level, byte by byte
-        uint8_t *pb = (uint8_t *)patch;
-        for (int i = lane; i < DS_W * DS_W; i += 64) {
-            const int r = i / DS_W, c = i - r * DS_W;
-            const int sy = orbx_reflect101(py0 + r, L.ph), sx = orbx_reflect101(px0 + c, L.pw);
-            pb[r * DS_PP + c] = img[(long long)sy * L.pitch + sx];
-        }
+#define DS_REQUEST(K)                                                                                                     \
+    {                                                                                                                     \
+        DS_GEOM(K)                                                                                                        \
+        if (interior) {                                                                                                   \
+            _Pragma("unroll") for (int k = 0; k < 9; ++k) {                                                               \
+                const int r = min(5 * k + rq, DS_W - 1);                                                                  \
+                tv[k] = lane0 < 60 ? *(const uint32_t *)(img + (long long)(py0 + r) * L.pitch + xa + 4 * dq) : 0u;         \
+            }                                                                                                             \
+        }                                                                                                                 \
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- orientation (IC_Angle, reference src/ORBextractor.cc:104-161) from the staged UN-blurred patch: lanes 0-31
-    // take the row +v, lanes 32-63 the row -v; integer moments reduced across the wave; fastAtan2 on every lane
-    float angle_deg;
-    {
-        const uint8_t *pc = (const uint8_t *)patch + DS_R * DS_PP + DS_R;   // the keypoint itself
-        const int u = (lane & 31) - ORBX_HALF_PATCH;                        // -15..16
-        const int sgn = lane < 32 ? 1 : -1;
-        int vals[ORBX_HALF_PATCH + 1];
+    DS_REQUEST(0)
+#pragma unroll 1
+    for (int ki = 0; ki < nk; ++ki) {
+        // everything below is re-derived from an opaque copy of the lane id: otherwise the loop-invariant per-lane
+        // values (pattern floats, LDS offsets, constants) are hoisted out of the loop and cost ~100 registers
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int4 pat = c_pattern_lane[lane];
+        DS_GEOM(ki)
+        const int slot = __builtin_amdgcn_readlane(slot_l, ki);
+        const int oi = o0 + ki;
+        // ---- stage the 43x43 patch (rows y-21.., columns x-21..): 12 ALIGNED dwords cover the 44 bytes of a patch
+        // row; dword d of the LDS row = funnel shift of aligned dwords d, d+1 (the neighbour lane's register, one DPP move)
+        if (interior) {
+            const uint32_t shift = (uint32_t)(px0 & 3);
 #pragma unroll
-        for (int v = 0; v <= ORBX_HALF_PATCH; ++v) vals[v] = pc[u + sgn * v * DS_PP];
-        int m10 = lane < 31 ? u * vals[0] : 0, m01 = 0;
-#pragma unroll
-        for (int v = 1; v <= ORBX_HALF_PATCH; ++v) {
-            const int d = g.umax[v];
-            const int val = (u >= -d && u <= d) ? vals[v] : 0;
-            m10 += u * val;
-            m01 += sgn * v * val;
-        }
-        m10 = orbx_wave_sum(m10);
-        m01 = orbx_wave_sum(m01);
-        angle_deg = orbx_fast_atan2((float)m01, (float)m10);
-        if (lane == 0) lvl_angle[(long long)f * g.kp_total + slot] = angle_deg;
-    }
-    // ---- row pass: h[r][c] for patch columns c+3 (c = 0..36 used); 4 outputs per item from 3 aligned dwords via
-    // v_alignbyte + v_dot4_u32_u8 with the packed 8-bit kernel {18,34,49,55 | 49,34,18,0}
-    for (int i = lane; i < DS_W * (DS_HC / 4); i += 64) {
-        const int r = i / (DS_HC / 4), q4 = i - r * (DS_HC / 4);
-        const uint32_t *w = patch + r * (DS_PP / 4) + q4;
-        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-        const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24), KHI = 49u | (34u << 8) | (18u << 16);
-        uint32_t hv[4];
-        hv[0] = __builtin_amdgcn_udot4(w0, KLO, __builtin_amdgcn_udot4(w1, KHI, 0u, false), false);
-#pragma unroll
-        for (int j = 1; j < 4; ++j)
-            hv[j] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, j), KLO,
-                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, j), KHI, 0u, false), false);
-        uint2 o;
-        o.x = hv[0] | (hv[1] << 16);   // each <= 255 * 257 = 65535
-        o.y = hv[2] | (hv[3] << 16);
-        *(uint2 *)(hrow + r * DS_HC + 4 * q4) = o;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- taps
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    const float angle = angle_deg * factorPI;
-    const OrbxSinCos sc = orbx_sincosf_pinned(angle);
-    const float a = sc.c, b = sc.s;
-    const int wvec = L.pw & ~3;
-    const float k0 = 55.f / 65536.f, k1 = 49.f / 65536.f, k2 = 34.f / 65536.f, k3 = 18.f / 65536.f;
-    const int pw4[4] = {pat.x, pat.y, pat.z, pat.w};
-    int tv[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const float px = (float)(signed char)((pw4[r] >> (16 * s2)) & 0xff);
-            const float py = (float)(signed char)((pw4[r] >> (16 * s2 + 8)) & 0xff);
-            float fy, fx;
-            if (g.fp_mode == ORBX_FP_GCC_FMA) {
-                fy = __builtin_fmaf(px, b, py * a);     // vfmadd132ss: x*b + rn(y*a)
-                fx = __builtin_fmaf(px, a, -(py * b));  // vfmsub132ss: x*a - rn(y*b)
-            } else {
-                fy = px * b + py * a;
-                fx = px * a - py * b;
+            for (int k = 0; k < 9; ++k) {
+                const uint32_t nxt = orbx_lane_above(tv[k]);
+                const int r = 5 * k + rq;
+                if (lane < 60 && dq < 11 && r < DS_W) patch[r * (DS_PP / 4) + dq] = __builtin_amdgcn_alignbyte(nxt, tv[k], shift);
             }
-            const int iy = (int)__builtin_rintf(fy), ix = (int)__builtin_rintf(fx);
-            // blurred pixel (x+ix, y+iy): column pass over h rows (iy+21-3 .. iy+21+3), h column ix+18
-            const uint16_t *hp = hrow + (iy + DS_R - 3) * DS_HC + (ix + DS_R - 3);
-            const int r0 = hp[3 * DS_HC], r1 = hp[2 * DS_HC] + hp[4 * DS_HC], r2 = hp[1 * DS_HC] + hp[5 * DS_HC],
-                      r3 = hp[0] + hp[6 * DS_HC];
-            // float column path for every lane; the integer tail (last w & 3 columns of the level) is evaluated only
-            // when some lane of the wave actually samples such a column (wave-uniform branch, almost never taken)
-            float s0 = (float)r0 * k0 + 0.f;
-            s0 = s0 + (float)r1 * k1;
-            s0 = s0 + (float)r2 * k2;
-            s0 = s0 + (float)r3 * k3;
-            int o = (int)__builtin_rintf(s0);
-            const bool tail = x + ix >= wvec;
-            if (__ballot(tail) != 0ull) {
-                const int oi2 = (55 * r0 + 49 * r1 + 34 * r2 + 18 * r3 + (1 << 15)) >> 16;
-                o = tail ? oi2 : o;
+        } else {
+            // image edge: reflect-101 of the padded level, byte by byte
+            uint8_t *pb = (uint8_t *)patch;
+            for (int i = lane; i < DS_W * DS_W; i += 64) {
+                const int r = i / DS_W, c = i - r * DS_W;
+                const int sy = orbx_reflect101(py0 + r, L.ph), sx = orbx_reflect101(px0 + c, L.pw);
+                pb[r * DS_PP + c] = img[(long long)sy * L.pitch + sx];
             }
-            tv[2 * r + s2] = min(max(o, 0), 255);
         }
-    }
-    unsigned long long words[4];
+        if (ki + 1 < nk) DS_REQUEST(ki + 1)
+        orbx_wave_sync();
+        if (dbg_stop == 1) continue;
+        // ---- orientation (IC_Angle, reference src/ORBextractor.cc:104-161) from the staged UN-blurred patch: lanes 0-31
+        // take the row +v, lanes 32-63 the row -v; integer moments reduced across the wave; fastAtan2 on every lane
+        float angle_deg;
+        {
+            const uint8_t *pc = (const uint8_t *)patch + DS_R * DS_PP + DS_R;   // the keypoint itself
+            const int u = (lane & 31) - ORBX_HALF_PATCH;                        // -15..16
+            const int sgn = lane < 32 ? 1 : -1;
+            int vals[ORBX_HALF_PATCH + 1];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) words[r] = __ballot(tv[2 * r] < tv[2 * r + 1]);
-    if (lane < 4) {
-        unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-        *(unsigned long long *)(desc + ((long long)f * cap + oi) * 32 + 8 * lane) = w;
+            for (int v = 0; v <= ORBX_HALF_PATCH; ++v) vals[v] = pc[u + sgn * v * DS_PP];
+            int m10 = lane < 31 ? u * vals[0] : 0, m01 = 0;
+#pragma unroll
+            for (int v = 1; v <= ORBX_HALF_PATCH; ++v) {
+                const int d = g.umax[v];
+                const int val = (u >= -d && u <= d) ? vals[v] : 0;
+                m10 += u * val;
+                m01 += sgn * v * val;
+            }
+            m10 = orbx_wave_sum(m10);
+            m01 = orbx_wave_sum(m01);
+            angle_deg = orbx_fast_atan2((float)m01, (float)m10);
+            if (lane == 0) lvl_angle[(long long)f * g.kp_total + slot] = angle_deg;
+        }
+        if (dbg_stop == 2) continue;
+        // ---- row pass: h[r][c] for patch columns c+3 (c = 0..36 used); 4 outputs per item from 3 aligned dwords via
+        // v_alignbyte + v_dot4_u32_u8 with the packed 8-bit kernel {18,34,49,55 | 49,34,18,0}
+        for (int i = lane; i < DS_W * (DS_HC / 4); i += 64) {
+            const int r = i / (DS_HC / 4), q4 = i - r * (DS_HC / 4);
+            const uint32_t *w = patch + r * (DS_PP / 4) + q4;
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24), KHI = 49u | (34u << 8) | (18u << 16);
+            uint32_t hv[4];
+            hv[0] = __builtin_amdgcn_udot4(w0, KLO, __builtin_amdgcn_udot4(w1, KHI, 0u, false), false);
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+                hv[j] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, j), KLO,
+                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, j), KHI, 0u, false), false);
+            uint2 o;
+            o.x = hv[0] | (hv[1] << 16);   // each <= 255 * 257 = 65535
+            o.y = hv[2] | (hv[3] << 16);
+            *(uint2 *)(hrow + r * DS_HC + 4 * q4) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (dbg_stop == 3) continue;
+        // ---- taps
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        const float angle = angle_deg * factorPI;
+        #ifdef DS_SINCOS_CALL
+        const OrbxSinCos sc = orbx_sincosf_call(angle);
+#else
+        const OrbxSinCos sc = orbx_sincosf_pinned(angle);
+#endif
+        const float a = sc.c, b = sc.s;
+        // Column pass at the tap position.  OpenCV's SSE2 column filter accumulates ((r0*k0 + r1*k1) + r2*k2) + r3*k3 in
+        // float with k = {55,49,34,18}/65536 and rounds to nearest-even for the columns x < (w & ~3); the last w & 3
+        // columns take its integer tail (I + 2^15) >> 16.  Every float product and every partial sum below 2^24 units of
+        // 2^-16 is exact, and a total >= 2^24 saturates to 255 either way, so the float path IS round-half-even(I / 65536)
+        // with I = 55 r0 + 49 r1 + 34 r2 + 18 r3: one integer formula serves both, the tail only changes the tie rule.
+        const int wvec = L.pw & ~3;
+        const int pw4[4] = {pat.x, pat.y, pat.z, pat.w};
+        int tval[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float px = (float)(signed char)((pw4[r] >> (16 * s2)) & 0xff);
+                const float py = (float)(signed char)((pw4[r] >> (16 * s2 + 8)) & 0xff);
+                float fy, fx;
+                if (g.fp_mode == ORBX_FP_GCC_FMA) {
+                    fy = __builtin_fmaf(px, b, py * a);     // vfmadd132ss: x*b + rn(y*a)
+                    fx = __builtin_fmaf(px, a, -(py * b));  // vfmsub132ss: x*a - rn(y*b)
+                } else {
+                    fy = px * b + py * a;
+                    fx = px * a - py * b;
+                }
+                const int iy = (int)__builtin_rintf(fy), ix = (int)__builtin_rintf(fx);
+                // blurred pixel (x+ix, y+iy): column pass over h rows (iy+21-3 .. iy+21+3), h column ix+18
+                const uint16_t *hp = hrow + (iy + DS_R - 3) * DS_HC + (ix + DS_R - 3);
+                const uint32_t r0 = hp[3 * DS_HC], r1 = (uint32_t)hp[2 * DS_HC] + hp[4 * DS_HC],
+                               r2 = (uint32_t)hp[1 * DS_HC] + hp[5 * DS_HC], r3 = (uint32_t)hp[0] + hp[6 * DS_HC];
+                const uint32_t I = __umul24(55u, r0) + __umul24(49u, r1) + __umul24(34u, r2) + __umul24(18u, r3);   // < 2^24.01
+                const uint32_t tie = x + ix >= wvec ? 1u : ((I >> 16) & 1u);   // half-up in the tail, half-even elsewhere
+                tval[2 * r + s2] = (int)min((I + 0x7fffu + tie) >> 16, 255u);
+            }
+        }
+        unsigned long long words[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) words[r] = orbx_ballot(tval[2 * r] < tval[2 * r + 1]);
+        if (lane < 4) {
+            unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+            *(unsigned long long *)(desc + ((long long)f * cap + oi) * 32 + 8 * lane) = w;
+        }
+        if (lane == 0) {
+            orbx_keypoint kp;
+            float fx = (float)x, fy = (float)y;
+            if (level != 0) { fx = fx * L.scale; fy = fy * L.scale; }
+            kp.x = fx; kp.y = fy;
+            kp.size = L.size;
+            kp.angle = angle_deg;
+            kp.response = (float)(pos >> 24);
+            kp.octave = level;
+            kp.class_id = -1;
+            kps[(long long)f * cap + oi] = kp;
+        }
+        orbx_wave_sync();   // the next keypoint overwrites patch / hrow
     }
-    if (lane == 0) {
-        orbx_keypoint kp;
-        float fx = (float)x, fy = (float)y;
-        if (level != 0) { fx = fx * L.scale; fy = fy * L.scale; }
-        kp.x = fx; kp.y = fy;
-        kp.size = L.size;
-        kp.angle = angle_deg;
-        kp.response = (float)(pos >> 24);
-        kp.octave = level;
-        kp.class_id = -1;
-        kps[(long long)f * cap + oi] = kp;
-    }
+#undef DS_GEOM
+#undef DS_REQUEST
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1885,8 +1920,10 @@ void orbx_launch_blur(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, 
 void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
                           const int *lvl_count, float *lvl_angle, orbx_keypoint *kps, uint8_t *desc,
                           int *counts, int *status, int cap) {
-    hipLaunchKernelGGL(k_describe, dim3(B, (g.kp_total + 3) / 4), dim3(256), 0, s, g, pyr, lvl_kp, lvl_count,
-                       lvl_angle, kps, desc, counts, status, cap);
+    static int dbg_stop = -1;
+    if (dbg_stop < 0) { const char *e = getenv("ORBX_DESC_STOP"); dbg_stop = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(k_describe, dim3(B, (g.kp_total + 4 * DS_KPW - 1) / (4 * DS_KPW)), dim3(256), 0, s, g, pyr, lvl_kp, lvl_count,
+                       lvl_angle, kps, desc, counts, status, cap, dbg_stop);
 }
 size_t orbx_match_workspace_bytes(int npairs, int out_stride) { return (size_t)npairs * MT_SPLIT * out_stride * sizeof(uint2); }
 void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,
