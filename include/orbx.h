@@ -203,6 +203,45 @@ orbx_status orbx_search_by_projection_mappoints(orbx_handle *h, const orbx_frame
                                                 const int32_t *frame_observations, const orbx_mappoint_view *mps,
                                                 float th, float nnratio, int32_t *assigned, int *nmatches);
 
+/* ---- BoW-guided policies.  Host code keeps the pointer chasing (KeyFrame / MapPoint /
+ * DBoW2 containers) and hands the fields the policies read as arrays; the Hamming distances come from the GPU, the
+ * order-dependent selection runs on the host exactly as the reference does. */
+/* DBoW2::FeatureVector = std::map<NodeId, std::vector<unsigned int>> (Thirdparty/DBoW2/DBoW2/FeatureVector.h), flattened
+ * in map order: node ids strictly ascending, n_nodes + 1 offsets into `index`, feature indices in each vector's order. */
+typedef struct orbx_featvec_view {
+    int32_t n_nodes;
+    const uint32_t *node_id;
+    const int32_t *begin;
+    const uint32_t *index;
+} orbx_featvec_view;
+typedef struct orbx_keyframe_view {
+    const orbx_keypoint *keys_un;    /* mvKeysUn */
+    const uint8_t *desc;             /* mDescriptors, n x 32 */
+    int32_t n;
+    const uint8_t *has_map_point;    /* GetMapPoint(i) != NULL && !isBad() */
+    const float *u_right;            /* mvuRight (SearchForTriangulation only) */
+    orbx_featvec_view feat_vec;      /* mFeatVec */
+    const float *scale_factors;      /* mvScaleFactors, per octave (SearchForTriangulation: second keyframe) */
+    const float *level_sigma2;       /* mvLevelSigma2, per octave (SearchForTriangulation: second keyframe) */
+} orbx_keyframe_view;
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) (src/ORBmatcher.cc:248-410;
+ * callers Tracking::TrackReferenceKeyFrame src/Tracking.cc:1281, Relocalization :2115).  f_keys = F.mvKeys (angle only).
+ * matched_kf[i] = index of the keyframe feature whose MapPoint is vpMapPointMatches[i], -1 = NULL. */
+orbx_status orbx_search_by_bow_keyframe_frame(orbx_handle *h, const orbx_keyframe_view *kf, const orbx_keypoint *f_keys,
+                                              const uint8_t *f_desc, int nf, const orbx_featvec_view *f_feat_vec,
+                                              float nnratio, int check_orientation, int32_t *matched_kf, int *nmatches);
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) (:722-866; caller
+ * LoopClosing::ComputeSim3).  matches12[i1] = index of the KF2 feature whose MapPoint is vpMatches12[i1], -1 = NULL. */
+orbx_status orbx_search_by_bow_keyframes(orbx_handle *h, const orbx_keyframe_view *kf1, const orbx_keyframe_view *kf2,
+                                         float nnratio, int check_orientation, int32_t *matches12, int *nmatches);
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (:879-1087, CheckDistEpipolarLine
+ * :206-233; caller LocalMapping::CreateNewMapPoints).  F12: row-major 3x3; (ex, ey): epipole of KF1's centre in KF2
+ * (:892-898, computed by the caller from its pose matrices).  vMatchedPairs = (i1, matches12[i1]) for ascending i1 with
+ * matches12[i1] >= 0.  The handle's fp_mode selects the contraction of the float expressions. */
+orbx_status orbx_search_for_triangulation(orbx_handle *h, const orbx_keyframe_view *kf1, const orbx_keyframe_view *kf2,
+                                          const float *F12, float ex, float ey, int only_stereo, int check_orientation,
+                                          int32_t *matches12, int *nmatches);
+
 /* ---- stream / timing plumbing ------------------------------------------------------------ */
 void *orbx_get_stream(orbx_handle *h);            /* hipStream_t */
 orbx_status orbx_set_stream(orbx_handle *h, void *hip_stream); /* NULL restores the private stream */

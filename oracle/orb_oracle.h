@@ -121,6 +121,27 @@ int orc_search_by_projection_mp(const orc_keypoint *kf, const uint8_t *df, const
                                 const float *view_cos, const uint8_t *mpdesc, const int *mp_obs, float th, float nnratio,
                                 int *assigned);
 
+/* ---- BoW-guided policies.  A DBoW2::FeatureVector is passed flattened: nn node ids (ascending), nn + 1 offsets,
+ * feature indices in each node's own order. */
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) src/ORBmatcher.cc:248-410; matched_kf[nf] out */
+int orc_search_by_bow_kf_frame(const orc_keypoint *kkf, const uint8_t *dkf, int nkf, const uint8_t *kf_has_mp,
+                               int nn_kf, const uint32_t *node_kf, const int *beg_kf, const uint32_t *idx_kf,
+                               const orc_keypoint *kf_, const uint8_t *df, int nf, int nn_f, const uint32_t *node_f,
+                               const int *beg_f, const uint32_t *idx_f, float nnratio, int check_ori, int *matched_kf);
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) :722-866; matches12[n1] out */
+int orc_search_by_bow_kf_kf(const orc_keypoint *k1, const uint8_t *d1, int n1, const uint8_t *has_mp1, int nn1,
+                            const uint32_t *node1, const int *beg1, const uint32_t *idx1v, const orc_keypoint *k2,
+                            const uint8_t *d2, int n2, const uint8_t *has_mp2, int nn2, const uint32_t *node2,
+                            const int *beg2, const uint32_t *idx2v, float nnratio, int check_ori, int *matches12);
+/* ORBmatcher::SearchForTriangulation :879-1087 with CheckDistEpipolarLine :206-233; matches12[n1] out */
+int orc_search_for_triangulation(const orc_keypoint *k1, const uint8_t *d1, int n1, const uint8_t *has_mp1,
+                                 const float *ur1, int nn1, const uint32_t *node1, const int *beg1,
+                                 const uint32_t *idx1v, const orc_keypoint *k2, const uint8_t *d2, int n2,
+                                 const uint8_t *has_mp2, const float *ur2, int nn2, const uint32_t *node2,
+                                 const int *beg2, const uint32_t *idx2v, const float *F12, float ex, float ey,
+                                 const float *scale_factors2, const float *level_sigma2_2, int only_stereo,
+                                 int check_ori, int fp_mode, int *matches12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,17 @@ def lib():
         L.orc_search_by_projection_mp.restype = C.c_int
         L.orc_search_by_projection_mp.argtypes = ([C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_int] +
                                                   [C.c_void_p] * 6 + [C.c_float, C.c_float, C.c_void_p])
+        L.orc_search_by_bow_kf_frame.restype = C.c_int
+        L.orc_search_by_bow_kf_frame.argtypes = ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3 +
+                                                 [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3 +
+                                                 [C.c_float, C.c_int, C.c_void_p])
+        L.orc_search_by_bow_kf_kf.restype = C.c_int
+        L.orc_search_by_bow_kf_kf.argtypes = ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3) * 2 + \
+                                             [C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_for_triangulation.restype = C.c_int
+        L.orc_search_for_triangulation.argtypes = ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] +
+                                                   [C.c_void_p] * 3) * 2 + [C.c_void_p, C.c_float, C.c_float, C.c_void_p,
+                                                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
@@ -282,3 +293,56 @@ def cvt_gray(img, rgb_order=True):
     out = np.zeros((h, w), np.uint8)
     lib().orc_cvt_gray(_p(img), w, h, img.strides[0], c, int(rgb_order), _p(out), w)
     return out
+
+
+def _flat_featvec(fv):
+    """dict {node: [indices]} -> (node_id u32 ascending, begin i32, index u32)"""
+    nodes = sorted(fv)
+    begin = np.zeros(len(nodes) + 1, np.int32)
+    for i, k in enumerate(nodes):
+        begin[i + 1] = begin[i] + len(fv[k])
+    return (np.array(nodes, np.uint32), begin, np.array([j for k in nodes for j in fv[k]], np.uint32))
+
+
+def search_by_bow_kf_frame(kf, f_keys, f_desc, f_fv, nnratio, check_ori=True):
+    kk, dk, has = (np.ascontiguousarray(kf["keys_un"], KP_DTYPE), np.ascontiguousarray(kf["desc"], np.uint8),
+                   np.ascontiguousarray(kf["has_map_point"], np.uint8))
+    n1, b1, i1 = _flat_featvec(kf["feat_vec"]); n2, b2, i2 = _flat_featvec(f_fv)
+    fk, fd = np.ascontiguousarray(f_keys, KP_DTYPE), np.ascontiguousarray(f_desc, np.uint8)
+    out = np.full(max(len(fk), 1), -1, np.int32)
+    n = lib().orc_search_by_bow_kf_frame(_p(kk), _p(dk), len(kk), _p(has), len(n1), _p(n1), _p(b1), _p(i1), _p(fk), _p(fd),
+                                         len(fk), len(n2), _p(n2), _p(b2), _p(i2), nnratio, int(check_ori), _p(out))
+    return n, out[:len(fk)].copy()
+
+
+def search_by_bow_kf_kf(kf1, kf2, nnratio, check_ori=True):
+    args = []
+    for kf in (kf1, kf2):
+        kk, dk, has = (np.ascontiguousarray(kf["keys_un"], KP_DTYPE), np.ascontiguousarray(kf["desc"], np.uint8),
+                       np.ascontiguousarray(kf["has_map_point"], np.uint8))
+        nn, bb, ii = _flat_featvec(kf["feat_vec"])
+        args.append((kk, dk, has, nn, bb, ii))
+    out = np.full(max(len(args[0][0]), 1), -1, np.int32)
+    flat = []
+    for (kk, dk, has, nn, bb, ii) in args:
+        flat += [_p(kk), _p(dk), len(kk), _p(has), len(nn), _p(nn), _p(bb), _p(ii)]
+    n = lib().orc_search_by_bow_kf_kf(*flat, nnratio, int(check_ori), _p(out))
+    return n, out[:len(args[0][0])].copy()
+
+
+def search_for_triangulation(kf1, kf2, F12, epipole, only_stereo=False, check_ori=True, fp_mode=FP_GCC_FMA):
+    args = []
+    for kf in (kf1, kf2):
+        kk, dk, has, ur = (np.ascontiguousarray(kf["keys_un"], KP_DTYPE), np.ascontiguousarray(kf["desc"], np.uint8),
+                           np.ascontiguousarray(kf["has_map_point"], np.uint8), np.ascontiguousarray(kf["u_right"], np.float32))
+        nn, bb, ii = _flat_featvec(kf["feat_vec"])
+        args.append((kk, dk, has, ur, nn, bb, ii))
+    out = np.full(max(len(args[0][0]), 1), -1, np.int32)
+    flat = []
+    for (kk, dk, has, ur, nn, bb, ii) in args:
+        flat += [_p(kk), _p(dk), len(kk), _p(has), _p(ur), len(nn), _p(nn), _p(bb), _p(ii)]
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sf = np.ascontiguousarray(kf2["scale_factors"], np.float32); s2 = np.ascontiguousarray(kf2["level_sigma2"], np.float32)
+    n = lib().orc_search_for_triangulation(*flat, _p(F), float(epipole[0]), float(epipole[1]), _p(sf), _p(s2),
+                                           int(only_stereo), int(check_ori), fp_mode, _p(out))
+    return n, out[:len(args[0][0])].copy()

@@ -433,3 +433,218 @@ int orc_search_by_projection_mp(const orc_keypoint *kf, const uint8_t *df, const
     free(occ); free(cands);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * BoW-guided policies.  DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>, ascending node id) is passed
+ * flattened: node ids (ascending), nn + 1 offsets, feature indices in the vector's own order.  Only matching node
+ * ids are visited; map::lower_bound of the reference's merge walk is the same as stepping through the sorted ids.
+ * ---------------------------------------------------------------------------------------------- */
+static void bow_rot_bin_push(int **hist, int *hn, float a1, float a2, int value) {
+    float rot = a1 - a2;                       /* src/ORBmatcher.cc:340-351 */
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * (HISTO_LENGTH / 360.0f));
+    if (bin == HISTO_LENGTH) bin = 0;
+    if (bin >= 0 && bin < HISTO_LENGTH) hist[bin][hn[bin]++] = value;
+}
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:248-410).
+ * matched_kf[nf]: index of the keyframe feature whose MapPoint was attached to frame feature i, -1 = NULL. */
+int orc_search_by_bow_kf_frame(const orc_keypoint *kkf, const uint8_t *dkf, int nkf, const uint8_t *kf_has_mp,
+                               int nn_kf, const uint32_t *node_kf, const int *beg_kf, const uint32_t *idx_kf,
+                               const orc_keypoint *kf_, const uint8_t *df, int nf, int nn_f, const uint32_t *node_f,
+                               const int *beg_f, const uint32_t *idx_f, float nnratio, int check_ori, int *matched_kf) {
+    (void)nkf;
+    int nmatches = 0;
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; ++i) { hist[i] = (int *)malloc(sizeof(int) * (size_t)(nf + 1)); hn[i] = 0; }
+    for (int i = 0; i < nf; ++i) matched_kf[i] = -1;
+    int a = 0, b = 0;
+    while (a < nn_kf && b < nn_f) {
+        if (node_kf[a] == node_f[b]) {
+            for (int ik = beg_kf[a]; ik < beg_kf[a + 1]; ++ik) {
+                const unsigned realIdxKF = idx_kf[ik];
+                if (!kf_has_mp[realIdxKF]) continue;                    /* !pMP || pMP->isBad()  (:285-291) */
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int jf = beg_f[b]; jf < beg_f[b + 1]; ++jf) {
+                    const unsigned realIdxF = idx_f[jf];
+                    if (matched_kf[realIdxF] >= 0) continue;             /* :305 */
+                    const int dist = orc_descriptor_distance(dkf + 32 * (size_t)realIdxKF, df + 32 * (size_t)realIdxF);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {   /* :328-331 */
+                    matched_kf[bestIdxF] = (int)realIdxKF;
+                    if (check_ori) bow_rot_bin_push(hist, hn, kkf[realIdxKF].angle, kf_[bestIdxF].angle, bestIdxF);
+                    nmatches++;
+                }
+            }
+            a++; b++;
+        } else if (node_kf[a] < node_f[b]) {
+            while (a < nn_kf && node_kf[a] < node_f[b]) a++;            /* lower_bound */
+        } else {
+            while (b < nn_f && node_f[b] < node_kf[a]) b++;
+        }
+    }
+    if (check_ori) {
+        int sizes[HISTO_LENGTH], i1, i2, i3;
+        for (int i = 0; i < HISTO_LENGTH; ++i) sizes[i] = hn[i];
+        orc_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int j = 0; j < hn[i]; ++j) { matched_kf[hist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (src/ORBmatcher.cc:722-866): loop-closure candidates.
+ * matches12[n1]: index of the KF2 feature whose MapPoint is vpMatches12[i1], -1 = NULL. */
+int orc_search_by_bow_kf_kf(const orc_keypoint *k1, const uint8_t *d1, int n1, const uint8_t *has_mp1, int nn1,
+                            const uint32_t *node1, const int *beg1, const uint32_t *idx1v, const orc_keypoint *k2,
+                            const uint8_t *d2, int n2, const uint8_t *has_mp2, int nn2, const uint32_t *node2,
+                            const int *beg2, const uint32_t *idx2v, float nnratio, int check_ori, int *matches12) {
+    int nmatches = 0;
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; ++i) { hist[i] = (int *)malloc(sizeof(int) * (size_t)(n1 + 1)); hn[i] = 0; }
+    uint8_t *matched2 = (uint8_t *)calloc((size_t)n2 + 1, 1);
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (node1[a] == node2[b]) {
+            for (int p = beg1[a]; p < beg1[a + 1]; ++p) {
+                const unsigned i1 = idx1v[p];
+                if (!has_mp1[i1]) continue;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int q = beg2[b]; q < beg2[b + 1]; ++q) {
+                    const unsigned i2 = idx2v[q];
+                    if (matched2[i2] || !has_mp2[i2]) continue;          /* :779-785 */
+                    const int dist = orc_descriptor_distance(d1 + 32 * (size_t)i1, d2 + 32 * (size_t)i2);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)i2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {    /* strict '<' here (:802) */
+                    matches12[i1] = bestIdx2;
+                    matched2[bestIdx2] = 1;
+                    if (check_ori) bow_rot_bin_push(hist, hn, k1[i1].angle, k2[bestIdx2].angle, (int)i1);
+                    nmatches++;
+                }
+            }
+            a++; b++;
+        } else if (node1[a] < node2[b]) {
+            while (a < nn1 && node1[a] < node2[b]) a++;
+        } else {
+            while (b < nn2 && node2[b] < node1[a]) b++;
+        }
+    }
+    if (check_ori) {
+        int sizes[HISTO_LENGTH], i1, i2, i3;
+        for (int i = 0; i < HISTO_LENGTH; ++i) sizes[i] = hn[i];
+        orc_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int j = 0; j < hn[i]; ++j) { matches12[hist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
+    free(matched2);
+    return nmatches;
+}
+
+/* ORBmatcher::CheckDistEpipolarLine (src/ORBmatcher.cc:206-233).  F12 row major 3x3.  The comparison is in double:
+ * 3.84 is a double literal. */
+static int orc_check_dist_epipolar(const orc_keypoint *kp1, const orc_keypoint *kp2, const float *F12, float sigma2,
+                                   int fp_mode) {
+    float a, b, c, num, den;
+    if (fp_mode == ORC_FP_GCC_FMA) {   /* g++ -O3 -march=native: the first product of each sum is fused */
+        a = fmaf(kp1->x, F12[0], kp1->y * F12[3]) + F12[6];
+        b = fmaf(kp1->x, F12[1], kp1->y * F12[4]) + F12[7];
+        c = fmaf(kp1->x, F12[2], kp1->y * F12[5]) + F12[8];
+        num = fmaf(a, kp2->x, b * kp2->y) + c;
+        den = fmaf(a, a, b * b);
+    } else {
+        a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];
+        b = kp1->x * F12[1] + kp1->y * F12[4] + F12[7];
+        c = kp1->x * F12[2] + kp1->y * F12[5] + F12[8];
+        num = a * kp2->x + b * kp2->y + c;
+        den = a * a + b * b;
+    }
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return (double)dsqr < 3.84 * (double)sigma2;
+}
+
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:879-1087; fork: vbMatched2 bookkeeping :1022,1069).
+ * (ex, ey) = epipole of KF1's centre in KF2 (:892-898, computed by the caller with its pose matrices).
+ * matches12[n1]: matched KF2 feature or -1; the reference's vMatchedPairs is (i, matches12[i]) for ascending i. */
+int orc_search_for_triangulation(const orc_keypoint *k1, const uint8_t *d1, int n1, const uint8_t *has_mp1,
+                                 const float *ur1, int nn1, const uint32_t *node1, const int *beg1,
+                                 const uint32_t *idx1v, const orc_keypoint *k2, const uint8_t *d2, int n2,
+                                 const uint8_t *has_mp2, const float *ur2, int nn2, const uint32_t *node2,
+                                 const int *beg2, const uint32_t *idx2v, const float *F12, float ex, float ey,
+                                 const float *scale_factors2, const float *level_sigma2_2, int only_stereo,
+                                 int check_ori, int fp_mode, int *matches12) {
+    int nmatches = 0;
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; ++i) { hist[i] = (int *)malloc(sizeof(int) * (size_t)(n1 + 1)); hn[i] = 0; }
+    uint8_t *matched2 = (uint8_t *)calloc((size_t)n2 + 1, 1);
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (node1[a] == node2[b]) {
+            for (int p = beg1[a]; p < beg1[a + 1]; ++p) {
+                const unsigned i1 = idx1v[p];
+                if (has_mp1[i1]) continue;                               /* already triangulated (:929-932) */
+                const int stereo1 = ur1[i1] >= 0;
+                if (only_stereo && !stereo1) continue;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int q = beg2[b]; q < beg2[b + 1]; ++q) {
+                    const unsigned i2 = idx2v[q];
+                    if (matched2[i2] || has_mp2[i2]) continue;
+                    const int stereo2 = ur2[i2] >= 0;
+                    if (only_stereo && !stereo2) continue;
+                    const int dist = orc_descriptor_distance(d1 + 32 * (size_t)i1, d2 + 32 * (size_t)i2);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const orc_keypoint *kp2 = &k2[i2];
+                    if (!stereo1 && !stereo2) {
+                        const float distex = ex - kp2->x, distey = ey - kp2->y;
+                        const float d2e = fp_mode == ORC_FP_GCC_FMA ? fmaf(distex, distex, distey * distey)
+                                                                    : distex * distex + distey * distey;
+                        if (d2e < 100 * scale_factors2[kp2->octave]) continue;
+                    }
+                    if (orc_check_dist_epipolar(&k1[i1], kp2, F12, level_sigma2_2[kp2->octave], fp_mode)) {
+                        bestIdx2 = (int)i2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    matches12[i1] = bestIdx2;
+                    matched2[bestIdx2] = 1;
+                    nmatches++;
+                    if (check_ori) bow_rot_bin_push(hist, hn, k1[i1].angle, k2[bestIdx2].angle, (int)i1);
+                }
+            }
+            a++; b++;
+        } else if (node1[a] < node2[b]) {
+            while (a < nn1 && node1[a] < node2[b]) a++;
+        } else {
+            while (b < nn2 && node2[b] < node1[a]) b++;
+        }
+    }
+    if (check_ori) {
+        int sizes[HISTO_LENGTH], i1, i2, i3;
+        for (int i = 0; i < HISTO_LENGTH; ++i) sizes[i] = hn[i];
+        orc_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int j = 0; j < hn[i]; ++j) {
+                matched2[matches12[hist[i][j]]] = 0;
+                matches12[hist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
+    free(matched2);
+    return nmatches;
+}

@@ -45,6 +45,16 @@ class MapPointView(C.Structure):
                 ("view_cos", C.c_void_p), ("desc", C.c_void_p), ("observations", C.c_void_p)]
 
 
+class FeatVecView(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("begin", C.c_void_p), ("index", C.c_void_p)]
+
+
+class KeyFrameView(C.Structure):
+    _fields_ = [("keys_un", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_int32), ("has_map_point", C.c_void_p),
+                ("u_right", C.c_void_p), ("feat_vec", FeatVecView), ("scale_factors", C.c_void_p),
+                ("level_sigma2", C.c_void_p)]
+
+
 class OrbxError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"orbx status {status}: {msg}")
@@ -62,7 +72,8 @@ SYMBOLS = [
     "orbx_kernel_name", "orbx_debug_candidates", "orbx_debug_level_keypoints", "orbx_debug_blur_copy",
     "orbx_grid_create", "orbx_grid_destroy", "orbx_grid_query", "orbx_three_maxima",
     "orbx_search_for_initialization", "orbx_stereo_match", "orbx_search_by_projection_frame",
-    "orbx_search_by_projection_mappoints", "orbx_set_input_format",
+    "orbx_search_by_projection_mappoints", "orbx_set_input_format", "orbx_search_by_bow_keyframe_frame",
+    "orbx_search_by_bow_keyframes", "orbx_search_for_triangulation",
 ]
 
 _lib = None
@@ -128,6 +139,15 @@ def lib():
     L.orbx_search_by_projection_mappoints.argtypes = [vp, C.POINTER(FrameView), vp, C.POINTER(MapPointView), f32, f32, vp,
                                                       C.POINTER(i32)]
     L.orbx_set_input_format.restype = i32; L.orbx_set_input_format.argtypes = [vp, i32]
+    L.orbx_search_by_bow_keyframe_frame.restype = i32
+    L.orbx_search_by_bow_keyframe_frame.argtypes = [vp, C.POINTER(KeyFrameView), vp, vp, i32, C.POINTER(FeatVecView), f32,
+                                                    i32, vp, C.POINTER(i32)]
+    L.orbx_search_by_bow_keyframes.restype = i32
+    L.orbx_search_by_bow_keyframes.argtypes = [vp, C.POINTER(KeyFrameView), C.POINTER(KeyFrameView), f32, i32, vp,
+                                               C.POINTER(i32)]
+    L.orbx_search_for_triangulation.restype = i32
+    L.orbx_search_for_triangulation.argtypes = [vp, C.POINTER(KeyFrameView), C.POINTER(KeyFrameView), vp, f32, f32, i32,
+                                                i32, vp, C.POINTER(i32)]
     _lib = L
     return L
 

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liborbx.so")
-SOURCES = ["orbx_kernels.hip", "orbx_api.cpp", "orbx_geometry.cpp"]
+SOURCES = ["orbx_kernels.hip", "orbx_api.cpp", "orbx_geometry.cpp", "orbx_policies.cpp"]
 HEADERS = ["orbx_device.h", "orbx_internal.h", "orbx_launch.h", "orbx_sincos.h",
            os.path.join("..", "..", "include", "orbx.h"), os.path.join("..", "..", "include", "orbx_pattern_data.h")]
 

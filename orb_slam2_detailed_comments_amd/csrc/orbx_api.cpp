@@ -72,6 +72,10 @@ struct orbx_handle {
     int launches[ORBX_K_COUNT] = {0};
 };
 
+// shared with orbx_policies.cpp
+orbx_status orbx_fail(orbx_status s, const std::string &msg) { return fail(s, msg); }
+int orbx_handle_fp_mode(const orbx_handle *h) { return h->p.fp_mode; }
+
 static const char *k_names[ORBX_K_COUNT] = {"k_pyr_l0", "k_pyr_resize", "k_fast_cells", "k_quadtree", "k_orient",
                                             "k_blur",   "k_describe",   "k_match",      "misc"};
 

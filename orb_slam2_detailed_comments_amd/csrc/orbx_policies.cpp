@@ -1,0 +1,237 @@
+// orbx_policies.cpp -- the BoW-guided ORBmatcher policies behind the C ABI:
+//   SearchByBoW(KeyFrame*, Frame&)        src/ORBmatcher.cc:248-410   (relocalisation / TrackReferenceKeyFrame)
+//   SearchByBoW(KeyFrame*, KeyFrame*)     src/ORBmatcher.cc:722-866   (loop-closure candidates)
+//   SearchForTriangulation                src/ORBmatcher.cc:879-1087  (LocalMapping::CreateNewMapPoints)
+// GPU: one Hamming matrix between the two descriptor sets (k_hamming_matrix through orbx_hamming_matrix).
+// Host: the merge walk over the two FeatureVectors and the order-dependent selection (a feature of the second set can
+// only be taken once, in the order the reference visits them), exactly as the reference runs it.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "orbx_internal.h"
+
+extern "C" orbx_status orbx_hamming_matrix(orbx_handle *h, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *dist);
+extern "C" void orbx_three_maxima(const int32_t *sizes, int L, int *ind1, int *ind2, int *ind3);
+orbx_status orbx_fail(orbx_status s, const std::string &msg);   // orbx_api.cpp: records orbx_last_error()
+int orbx_handle_fp_mode(const orbx_handle *h);
+
+namespace {
+const int HISTO = 30, TH_LOW_ = 50;
+
+struct RotHist {
+    std::vector<int> bins[HISTO];
+    void push(float a1, float a2, int value) {   // src/ORBmatcher.cc:340-351
+        float rot = a1 - a2;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * (HISTO / 360.0f));
+        if (bin == HISTO) bin = 0;
+        if (bin >= 0 && bin < HISTO) bins[bin].push_back(value);
+    }
+    template <class F> void reject_minor(F &&drop) {   // ComputeThreeMaxima + the removal loop (:380-398)
+        int32_t sizes[HISTO]; int i1, i2, i3;
+        for (int i = 0; i < HISTO; ++i) sizes[i] = (int32_t)bins[i].size();
+        orbx_three_maxima(sizes, HISTO, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO; ++i) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int v : bins[i]) drop(v);
+        }
+    }
+};
+
+bool featvec_ok(const orbx_featvec_view &fv, int nfeat) {
+    if (fv.n_nodes < 0) return false;
+    if (fv.n_nodes == 0) return true;
+    if (!fv.node_id || !fv.begin || (fv.begin[fv.n_nodes] > 0 && !fv.index)) return false;
+    if (fv.begin[0] != 0) return false;
+    for (int i = 0; i < fv.n_nodes; ++i) {
+        if (fv.begin[i + 1] < fv.begin[i]) return false;
+        if (i > 0 && fv.node_id[i] <= fv.node_id[i - 1]) return false;   // std::map order
+    }
+    for (int i = 0; i < fv.begin[fv.n_nodes]; ++i)
+        if (fv.index[i] >= (uint32_t)nfeat) return false;
+    return true;
+}
+
+// the reference's merge walk with map::lower_bound; `on_node(a, b)` for every common node id
+template <class F> void walk_common_nodes(const orbx_featvec_view &f1, const orbx_featvec_view &f2, F &&on_node) {
+    int a = 0, b = 0;
+    while (a < f1.n_nodes && b < f2.n_nodes) {
+        if (f1.node_id[a] == f2.node_id[b]) { on_node(a, b); ++a; ++b; }
+        else if (f1.node_id[a] < f2.node_id[b]) { while (a < f1.n_nodes && f1.node_id[a] < f2.node_id[b]) ++a; }
+        else { while (b < f2.n_nodes && f2.node_id[b] < f1.node_id[a]) ++b; }
+    }
+}
+}  // namespace
+
+extern "C" orbx_status orbx_search_by_bow_keyframe_frame(orbx_handle *h, const orbx_keyframe_view *kf,
+                                                         const orbx_keypoint *f_keys, const uint8_t *f_desc, int nf,
+                                                         const orbx_featvec_view *f_fv, float nnratio,
+                                                         int check_orientation, int32_t *matched_kf, int *nmatches_out) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!kf || !f_fv || nf < 0 || kf->n < 0 || !matched_kf || !nmatches_out || (nf > 0 && (!f_keys || !f_desc)) ||
+        (kf->n > 0 && (!kf->keys_un || !kf->desc || !kf->has_map_point)))
+        return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    if (!featvec_ok(kf->feat_vec, kf->n) || !featvec_ok(*f_fv, nf)) return orbx_fail(ORBX_BAD_ARGUMENT, "malformed feature vector");
+    *nmatches_out = 0;
+    for (int i = 0; i < nf; ++i) matched_kf[i] = -1;
+    if (nf == 0 || kf->n == 0) return ORBX_OK;
+    std::vector<uint16_t> D((size_t)kf->n * nf);
+    orbx_status st = orbx_hamming_matrix(h, kf->desc, kf->n, f_desc, nf, D.data());
+    if (st != ORBX_OK) return st;
+    int nmatches = 0;
+    RotHist hist;
+    const orbx_featvec_view &fk = kf->feat_vec;
+    walk_common_nodes(fk, *f_fv, [&](int a, int b) {
+        for (int ik = fk.begin[a]; ik < fk.begin[a + 1]; ++ik) {
+            const uint32_t iKF = fk.index[ik];
+            if (!kf->has_map_point[iKF]) continue;
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            const uint16_t *row = &D[(size_t)iKF * nf];
+            for (int jf = f_fv->begin[b]; jf < f_fv->begin[b + 1]; ++jf) {
+                const uint32_t iF = f_fv->index[jf];
+                if (matched_kf[iF] >= 0) continue;
+                const int dist = row[iF];
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)iF; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 <= TH_LOW_ && (float)bestDist1 < nnratio * (float)bestDist2) {
+                matched_kf[bestIdxF] = (int32_t)iKF;
+                if (check_orientation) hist.push(kf->keys_un[iKF].angle, f_keys[bestIdxF].angle, bestIdxF);
+                nmatches++;
+            }
+        }
+    });
+    if (check_orientation) hist.reject_minor([&](int iF) { matched_kf[iF] = -1; nmatches--; });
+    *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_search_by_bow_keyframes(orbx_handle *h, const orbx_keyframe_view *kf1,
+                                                    const orbx_keyframe_view *kf2, float nnratio, int check_orientation,
+                                                    int32_t *matches12, int *nmatches_out) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!kf1 || !kf2 || kf1->n < 0 || kf2->n < 0 || !matches12 || !nmatches_out ||
+        (kf1->n > 0 && (!kf1->keys_un || !kf1->desc || !kf1->has_map_point)) ||
+        (kf2->n > 0 && (!kf2->keys_un || !kf2->desc || !kf2->has_map_point)))
+        return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    if (!featvec_ok(kf1->feat_vec, kf1->n) || !featvec_ok(kf2->feat_vec, kf2->n)) return orbx_fail(ORBX_BAD_ARGUMENT, "malformed feature vector");
+    *nmatches_out = 0;
+    for (int i = 0; i < kf1->n; ++i) matches12[i] = -1;
+    if (kf1->n == 0 || kf2->n == 0) return ORBX_OK;
+    const int n2 = kf2->n;
+    std::vector<uint16_t> D((size_t)kf1->n * n2);
+    orbx_status st = orbx_hamming_matrix(h, kf1->desc, kf1->n, kf2->desc, n2, D.data());
+    if (st != ORBX_OK) return st;
+    int nmatches = 0;
+    RotHist hist;
+    std::vector<uint8_t> matched2((size_t)n2, 0);
+    const orbx_featvec_view &f1 = kf1->feat_vec, &f2 = kf2->feat_vec;
+    walk_common_nodes(f1, f2, [&](int a, int b) {
+        for (int p = f1.begin[a]; p < f1.begin[a + 1]; ++p) {
+            const uint32_t i1 = f1.index[p];
+            if (!kf1->has_map_point[i1]) continue;
+            int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+            const uint16_t *row = &D[(size_t)i1 * n2];
+            for (int q = f2.begin[b]; q < f2.begin[b + 1]; ++q) {
+                const uint32_t i2 = f2.index[q];
+                if (matched2[i2] || !kf2->has_map_point[i2]) continue;
+                const int dist = row[i2];
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)i2; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 < TH_LOW_ && (float)bestDist1 < nnratio * (float)bestDist2) {   // strict '<' (:802)
+                matches12[i1] = bestIdx2;
+                matched2[bestIdx2] = 1;
+                if (check_orientation) hist.push(kf1->keys_un[i1].angle, kf2->keys_un[bestIdx2].angle, (int)i1);
+                nmatches++;
+            }
+        }
+    });
+    if (check_orientation) hist.reject_minor([&](int i1) { matches12[i1] = -1; nmatches--; });
+    *nmatches_out = nmatches;
+    return ORBX_OK;
+}
+
+// ORBmatcher::CheckDistEpipolarLine (src/ORBmatcher.cc:206-233); the final comparison is in double (3.84 is a double)
+static bool check_dist_epipolar(const orbx_keypoint &kp1, const orbx_keypoint &kp2, const float *F12, float sigma2, bool fma_mode) {
+    float a, b, c, num, den;
+    if (fma_mode) {   // g++ -O3 -march=native fuses the first product of each sum
+        a = std::fmaf(kp1.x, F12[0], kp1.y * F12[3]) + F12[6];
+        b = std::fmaf(kp1.x, F12[1], kp1.y * F12[4]) + F12[7];
+        c = std::fmaf(kp1.x, F12[2], kp1.y * F12[5]) + F12[8];
+        num = std::fmaf(a, kp2.x, b * kp2.y) + c;
+        den = std::fmaf(a, a, b * b);
+    } else {
+        a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+        b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+        c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+        num = a * kp2.x + b * kp2.y + c;
+        den = a * a + b * b;
+    }
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return (double)dsqr < 3.84 * (double)sigma2;
+}
+
+extern "C" orbx_status orbx_search_for_triangulation(orbx_handle *h, const orbx_keyframe_view *kf1,
+                                                     const orbx_keyframe_view *kf2, const float *F12, float ex, float ey,
+                                                     int only_stereo, int check_orientation, int32_t *matches12,
+                                                     int *nmatches_out) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!kf1 || !kf2 || !F12 || kf1->n < 0 || kf2->n < 0 || !matches12 || !nmatches_out ||
+        (kf1->n > 0 && (!kf1->keys_un || !kf1->desc || !kf1->has_map_point || !kf1->u_right)) ||
+        (kf2->n > 0 && (!kf2->keys_un || !kf2->desc || !kf2->has_map_point || !kf2->u_right || !kf2->scale_factors ||
+                        !kf2->level_sigma2)))
+        return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    if (!featvec_ok(kf1->feat_vec, kf1->n) || !featvec_ok(kf2->feat_vec, kf2->n)) return orbx_fail(ORBX_BAD_ARGUMENT, "malformed feature vector");
+    *nmatches_out = 0;
+    for (int i = 0; i < kf1->n; ++i) matches12[i] = -1;
+    if (kf1->n == 0 || kf2->n == 0) return ORBX_OK;
+    const int n2 = kf2->n;
+    const bool fma_mode = orbx_handle_fp_mode(h) == ORBX_FP_GCC_FMA;
+    std::vector<uint16_t> D((size_t)kf1->n * n2);
+    orbx_status st = orbx_hamming_matrix(h, kf1->desc, kf1->n, kf2->desc, n2, D.data());
+    if (st != ORBX_OK) return st;
+    int nmatches = 0;
+    RotHist hist;
+    std::vector<uint8_t> matched2((size_t)n2, 0);
+    const orbx_featvec_view &f1 = kf1->feat_vec, &f2 = kf2->feat_vec;
+    walk_common_nodes(f1, f2, [&](int a, int b) {
+        for (int p = f1.begin[a]; p < f1.begin[a + 1]; ++p) {
+            const uint32_t i1 = f1.index[p];
+            if (kf1->has_map_point[i1]) continue;                       // already triangulated (:929-932)
+            const bool stereo1 = kf1->u_right[i1] >= 0;
+            if (only_stereo && !stereo1) continue;
+            const orbx_keypoint &kp1 = kf1->keys_un[i1];
+            int bestDist = TH_LOW_, bestIdx2 = -1;
+            const uint16_t *row = &D[(size_t)i1 * n2];
+            for (int q = f2.begin[b]; q < f2.begin[b + 1]; ++q) {
+                const uint32_t i2 = f2.index[q];
+                if (matched2[i2] || kf2->has_map_point[i2]) continue;
+                const bool stereo2 = kf2->u_right[i2] >= 0;
+                if (only_stereo && !stereo2) continue;
+                const int dist = row[i2];
+                if (dist > TH_LOW_ || dist > bestDist) continue;
+                const orbx_keypoint &kp2 = kf2->keys_un[i2];
+                if (!stereo1 && !stereo2) {                              // too close to the epipole (:996-1003)
+                    const float distex = ex - kp2.x, distey = ey - kp2.y;
+                    const float d2e = fma_mode ? std::fmaf(distex, distex, distey * distey) : distex * distex + distey * distey;
+                    if (d2e < 100 * kf2->scale_factors[kp2.octave]) continue;
+                }
+                if (check_dist_epipolar(kp1, kp2, F12, kf2->level_sigma2[kp2.octave], fma_mode)) { bestIdx2 = (int)i2; bestDist = dist; }
+            }
+            if (bestIdx2 >= 0) {
+                matches12[i1] = bestIdx2;
+                matched2[bestIdx2] = 1;                                  // fork (:1022)
+                nmatches++;
+                if (check_orientation) hist.push(kp1.angle, kf2->keys_un[bestIdx2].angle, (int)i1);
+            }
+        }
+    });
+    if (check_orientation)
+        hist.reject_minor([&](int i1) { matched2[matches12[i1]] = 0; matches12[i1] = -1; nmatches--; });   // fork (:1069)
+    *nmatches_out = nmatches;
+    return ORBX_OK;
+}

@@ -105,6 +105,75 @@ class ORBmatcher:
                                                           float(self.mfNNratio), ptr(out), C.byref(n)))
         return n.value, out[:F.N].copy()
 
+    # ---- BoW-guided policies (src/ORBmatcher.cc:248-410, 722-866, 879-1087)
+    @staticmethod
+    def _featvec(fv, keep):
+        """fv: dict {node_id: [feature indices]} (DBoW2::FeatureVector) or (node_id, begin, index) arrays"""
+        if isinstance(fv, dict):
+            nodes = sorted(fv)
+            begin = np.zeros(len(nodes) + 1, np.int32)
+            for i, k in enumerate(nodes):
+                begin[i + 1] = begin[i] + len(fv[k])
+            index = np.array([j for k in nodes for j in fv[k]], np.uint32)
+            node_id = np.array(nodes, np.uint32)
+        else:
+            node_id, begin, index = (np.ascontiguousarray(a, t) for a, t in zip(fv, (np.uint32, np.int32, np.uint32)))
+        keep += [node_id, begin, index]
+        v = _capi.FeatVecView()
+        v.n_nodes = len(node_id)
+        v.node_id, v.begin, v.index = node_id.ctypes.data, begin.ctypes.data, index.ctypes.data
+        return v
+
+    def _kf_view(self, kf, keep):
+        """kf: dict with keys_un, desc, has_map_point, feat_vec and optionally u_right, scale_factors, level_sigma2"""
+        a = lambda x, t: np.ascontiguousarray(x, t)
+        keys, desc, has = a(kf["keys_un"], _capi.KP_DTYPE), a(kf["desc"], np.uint8), a(kf["has_map_point"], np.uint8)
+        keep += [keys, desc, has]
+        v = _capi.KeyFrameView()
+        v.keys_un, v.desc, v.n, v.has_map_point = keys.ctypes.data, desc.ctypes.data, len(keys), has.ctypes.data
+        for name, t in (("u_right", np.float32), ("scale_factors", np.float32), ("level_sigma2", np.float32)):
+            if kf.get(name) is not None:
+                arr = a(kf[name], t); keep.append(arr); setattr(v, name, arr.ctypes.data)
+        v.feat_vec = self._featvec(kf["feat_vec"], keep)
+        return v
+
+    def SearchByBoW(self, kf, f_keys, f_desc, f_feat_vec):
+        """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches).  Returns (nmatches, matched_kf[F.N])."""
+        import ctypes as C
+        keep = []
+        kv = self._kf_view(kf, keep)
+        fk, fd = np.ascontiguousarray(f_keys, _capi.KP_DTYPE), np.ascontiguousarray(f_desc, np.uint8)
+        fv = self._featvec(f_feat_vec, keep)
+        out = np.full(max(len(fk), 1), -1, np.int32)
+        n = C.c_int(0)
+        check(self._L.orbx_search_by_bow_keyframe_frame(self._ex.handle, C.byref(kv), ptr(fk), ptr(fd), len(fk), C.byref(fv),
+                                                        float(self.mfNNratio), int(self.mbCheckOrientation), ptr(out), C.byref(n)))
+        return n.value, out[:len(fk)].copy()
+
+    def SearchByBoWKeyFrames(self, kf1, kf2):
+        """SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12).  Returns (nmatches, matches12[KF1.N])."""
+        import ctypes as C
+        keep = []
+        v1, v2 = self._kf_view(kf1, keep), self._kf_view(kf2, keep)
+        out = np.full(max(v1.n, 1), -1, np.int32)
+        n = C.c_int(0)
+        check(self._L.orbx_search_by_bow_keyframes(self._ex.handle, C.byref(v1), C.byref(v2), float(self.mfNNratio),
+                                                   int(self.mbCheckOrientation), ptr(out), C.byref(n)))
+        return n.value, out[:v1.n].copy()
+
+    def SearchForTriangulation(self, kf1, kf2, F12, epipole, bOnlyStereo=False):
+        """Returns (nmatches, matches12[KF1.N]); vMatchedPairs = [(i, m) for i, m in enumerate(matches12) if m >= 0]."""
+        import ctypes as C
+        keep = []
+        v1, v2 = self._kf_view(kf1, keep), self._kf_view(kf2, keep)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        out = np.full(max(v1.n, 1), -1, np.int32)
+        n = C.c_int(0)
+        check(self._L.orbx_search_for_triangulation(self._ex.handle, C.byref(v1), C.byref(v2), ptr(F), float(epipole[0]),
+                                                    float(epipole[1]), int(bOnlyStereo), int(self.mbCheckOrientation),
+                                                    ptr(out), C.byref(n)))
+        return n.value, out[:v1.n].copy()
+
     # ---- ComputeThreeMaxima (src/ORBmatcher.cc:2026-2068): 30 numbers, host side
     @staticmethod
     def ComputeThreeMaxima(sizes):

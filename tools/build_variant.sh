@@ -5,4 +5,4 @@ cd "$(dirname "$0")/.."
 mkdir -p tools/bin
 S=orb_slam2_detailed_comments_amd/csrc
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip -ffp-contract=off -fno-fast-math -w "$@" \
-  $S/orbx_kernels.hip $S/orbx_api.cpp $S/orbx_geometry.cpp -o tools/bin/liborbx_$name.so
+  $S/orbx_kernels.hip $S/orbx_api.cpp $S/orbx_geometry.cpp $S/orbx_policies.cpp -o tools/bin/liborbx_$name.so
