@@ -242,6 +242,54 @@ orbx_status orbx_search_for_triangulation(orbx_handle *h, const orbx_keyframe_vi
                                           const float *F12, float ex, float ey, int only_stereo, int check_orientation,
                                           int32_t *matches12, int *nmatches);
 
+/* ---- projection-guided back-end policies.  The pose algebra in front of them (cv::Mat products, cv::norm,
+ * MapPoint::PredictScale: OpenCV / libm code) stays in the maintainer's shim, which IS the reference's code; the entry
+ * points start where the reference holds, for every MapPoint, "passed every geometric test", the projection, the
+ * predicted level and the representative descriptor. */
+typedef struct orbx_projected_points {
+    int32_t n;
+    const uint8_t *valid;     /* the point reaches `const float radius = th * ...` in the reference */
+    const float *uv;          /* projection (u, v), 2 floats per point */
+    const float *u_right;     /* ur = u - bf * invz (orbx_fuse only) */
+    const int32_t *level;     /* nPredictedLevel */
+    const uint8_t *desc;      /* pMP->GetDescriptor(), 32 bytes per point */
+    const float *angle;       /* pKF->mvKeysUn[i].angle (orbx_search_by_projection_keyframe with check_orientation) */
+} orbx_projected_points;
+typedef struct orbx_target_view {   /* the KeyFrame / Frame whose features are searched */
+    const orbx_keypoint *keys_un;    /* mvKeysUn */
+    const uint8_t *desc;             /* mDescriptors */
+    const float *u_right;            /* mvuRight (orbx_fuse only) */
+    int32_t n;
+    float min_x, max_x, min_y, max_y; /* mnMinX .. mnMaxY (grid of GetFeaturesInArea) */
+    const float *scale_factors;      /* mvScaleFactors */
+    const float *inv_level_sigma2;   /* mvInvLevelSigma2 (orbx_fuse only) */
+} orbx_target_view;
+/* ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th) (src/ORBmatcher.cc:1100-1280), lines
+ * :1168-1245: best_idx[i] = keyframe feature the point is fused into, -1 = none.  The caller then runs the Replace /
+ * AddObservation / AddMapPoint branch (:1248-1275) over i in order; it does not feed back into the selection. */
+orbx_status orbx_fuse(orbx_handle *h, const orbx_target_view *kf, const orbx_projected_points *pts, float th,
+                      int32_t *best_idx, int *nfused);
+/* ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint) (:1282-1430), lines :1345-1400 */
+orbx_status orbx_fuse_sim3(orbx_handle *h, const orbx_target_view *kf, const orbx_projected_points *pts, float th,
+                           int32_t *best_idx, int *nfused);
+/* ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, vpPoints, vpMatched, int th) (:415-560), lines :498-556.
+ * matched[idx] = vpMatched[idx] != NULL, updated exactly as the reference updates vpMatched (point order matters);
+ * best_idx[i] = feature that received point i, -1 = none. */
+orbx_status orbx_search_by_projection_sim3(orbx_handle *h, const orbx_target_view *kf, const orbx_projected_points *pts,
+                                           int th, uint8_t *matched, int32_t *best_idx, int *nmatches);
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (:1433-1690) from the two projection loops on.
+ * pts1_in_2: one entry per KF1 feature (valid = has a good MapPoint, !vbAlreadyMatched1, all geometric tests), projected
+ * into KF2; pts2_in_1 the converse.  matches12[i1] = KF2 feature whose MapPoint becomes vpMatches12[i1], -1 otherwise. */
+orbx_status orbx_search_by_sim3(orbx_handle *h, const orbx_target_view *kf1, const orbx_target_view *kf2,
+                                const orbx_projected_points *pts1_in_2, const orbx_projected_points *pts2_in_1, float th,
+                                int32_t *matches12, int *nfound);
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) (:1873-2020; caller
+ * Tracking::Relocalization).  pts = pKF's MapPoints; cur_has_map_point[i2] = CurrentFrame.mvpMapPoints[i2] != NULL
+ * (in/out); matched_point[i2] = index of the point attached to feature i2, -1. */
+orbx_status orbx_search_by_projection_keyframe(orbx_handle *h, const orbx_target_view *cur, const orbx_projected_points *pts,
+                                               float th, int orb_dist, int check_orientation, uint8_t *cur_has_map_point,
+                                               int32_t *matched_point, int *nmatches);
+
 /* ---- stream / timing plumbing ------------------------------------------------------------ */
 void *orbx_get_stream(orbx_handle *h);            /* hipStream_t */
 orbx_status orbx_set_stream(orbx_handle *h, void *hip_stream); /* NULL restores the private stream */

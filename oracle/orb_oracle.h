@@ -142,6 +142,28 @@ int orc_search_for_triangulation(const orc_keypoint *k1, const uint8_t *d1, int 
                                  const float *scale_factors2, const float *level_sigma2_2, int only_stereo,
                                  int check_ori, int fp_mode, int *matches12);
 
+/* ---- projection-guided back-end policies, from the point where the reference holds (valid, u, v[, ur], predicted level,
+ * descriptor) of every MapPoint (the cv::Mat pose algebra in front stays in the reference's translation unit) */
+int orc_fuse(const orc_keypoint *kk, const uint8_t *dk, const float *ur_k, int nk, float minx, float maxx, float miny,
+             float maxy, const float *scale_factors, const float *inv_level_sigma2, int np, const uint8_t *valid,
+             const float *uv, const float *ur, const int *level, const uint8_t *desc, float th, int fp_mode,
+             int *best_idx);
+int orc_fuse_sim3(const orc_keypoint *kk, const uint8_t *dk, int nk, float minx, float maxx, float miny, float maxy,
+                  const float *scale_factors, int np, const uint8_t *valid, const float *uv, const int *level,
+                  const uint8_t *desc, float th, int *best_idx);
+int orc_search_by_projection_sim3(const orc_keypoint *kk, const uint8_t *dk, int nk, float minx, float maxx, float miny,
+                                  float maxy, const float *scale_factors, int np, const uint8_t *valid, const float *uv,
+                                  const int *level, const uint8_t *desc, int th, uint8_t *matched, int *best_idx);
+int orc_search_by_sim3(const orc_keypoint *k1, const uint8_t *d1, int n1, const float *bounds1, const float *sf1,
+                       const orc_keypoint *k2, const uint8_t *d2, int n2, const float *bounds2, const float *sf2,
+                       const uint8_t *valid1, const float *uv1in2, const int *level1in2, const uint8_t *mpdesc1,
+                       const uint8_t *valid2, const float *uv2in1, const int *level2in1, const uint8_t *mpdesc2, float th,
+                       int *matches12);
+int orc_search_by_projection_kf(const orc_keypoint *kc, const uint8_t *dc, int nc, float minx, float maxx, float miny,
+                                float maxy, const float *scale_factors, int np, const uint8_t *valid, const float *uv,
+                                const int *level, const uint8_t *desc, const float *kf_angle, float th, int orb_dist,
+                                int check_ori, uint8_t *cur_has_mp, int *matched_point);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,17 @@ def lib():
         L.orc_search_for_triangulation.argtypes = ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] +
                                                    [C.c_void_p] * 3) * 2 + [C.c_void_p, C.c_float, C.c_float, C.c_void_p,
                                                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        vp_, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.orc_fuse.restype = ci
+        L.orc_fuse.argtypes = [vp_, vp_, vp_, ci, cf, cf, cf, cf, vp_, vp_, ci, vp_, vp_, vp_, vp_, vp_, cf, ci, vp_]
+        L.orc_fuse_sim3.restype = ci
+        L.orc_fuse_sim3.argtypes = [vp_, vp_, ci, cf, cf, cf, cf, vp_, ci, vp_, vp_, vp_, vp_, cf, vp_]
+        L.orc_search_by_projection_sim3.restype = ci
+        L.orc_search_by_projection_sim3.argtypes = [vp_, vp_, ci, cf, cf, cf, cf, vp_, ci, vp_, vp_, vp_, vp_, ci, vp_, vp_]
+        L.orc_search_by_sim3.restype = ci
+        L.orc_search_by_sim3.argtypes = [vp_, vp_, ci, vp_, vp_] * 2 + [vp_] * 8 + [cf, vp_]
+        L.orc_search_by_projection_kf.restype = ci
+        L.orc_search_by_projection_kf.argtypes = [vp_, vp_, ci, cf, cf, cf, cf, vp_, ci, vp_, vp_, vp_, vp_, vp_, cf, ci, ci, vp_, vp_]
         L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
@@ -346,3 +357,57 @@ def search_for_triangulation(kf1, kf2, F12, epipole, only_stereo=False, check_or
     n = lib().orc_search_for_triangulation(*flat, _p(F), float(epipole[0]), float(epipole[1]), _p(sf), _p(s2),
                                            int(only_stereo), int(check_ori), fp_mode, _p(out))
     return n, out[:len(args[0][0])].copy()
+
+
+def _tgt(t):
+    return (np.ascontiguousarray(t["keys_un"], KP_DTYPE), np.ascontiguousarray(t["desc"], np.uint8),
+            [float(b) for b in t["bounds"]], np.ascontiguousarray(t["scale_factors"], np.float32))
+
+
+def _pts(p):
+    return (np.ascontiguousarray(p["valid"], np.uint8), np.ascontiguousarray(p["uv"], np.float32),
+            np.ascontiguousarray(p["level"], np.int32), np.ascontiguousarray(p["desc"], np.uint8))
+
+
+def fuse(kf, pts, th, fp_mode=FP_GCC_FMA):
+    k, d, b, sf = _tgt(kf); v, uv, lv, pd = _pts(pts)
+    urk = np.ascontiguousarray(kf["u_right"], np.float32); is2 = np.ascontiguousarray(kf["inv_level_sigma2"], np.float32)
+    ur = np.ascontiguousarray(pts["u_right"], np.float32)
+    out = np.full(max(len(v), 1), -1, np.int32)
+    n = lib().orc_fuse(_p(k), _p(d), _p(urk), len(k), *b, _p(sf), _p(is2), len(v), _p(v), _p(uv), _p(ur), _p(lv), _p(pd), th,
+                       fp_mode, _p(out))
+    return n, out[:len(v)].copy()
+
+
+def fuse_sim3(kf, pts, th):
+    k, d, b, sf = _tgt(kf); v, uv, lv, pd = _pts(pts)
+    out = np.full(max(len(v), 1), -1, np.int32)
+    n = lib().orc_fuse_sim3(_p(k), _p(d), len(k), *b, _p(sf), len(v), _p(v), _p(uv), _p(lv), _p(pd), th, _p(out))
+    return n, out[:len(v)].copy()
+
+
+def search_by_projection_sim3(kf, pts, matched, th):
+    k, d, b, sf = _tgt(kf); v, uv, lv, pd = _pts(pts)
+    out = np.full(max(len(v), 1), -1, np.int32)
+    n = lib().orc_search_by_projection_sim3(_p(k), _p(d), len(k), *b, _p(sf), len(v), _p(v), _p(uv), _p(lv), _p(pd), int(th),
+                                            _p(matched), _p(out))
+    return n, out[:len(v)].copy()
+
+
+def search_by_sim3(kf1, kf2, p12, p21, th):
+    k1, d1, b1, sf1 = _tgt(kf1); k2, d2, b2, sf2 = _tgt(kf2)
+    v1, uv1, lv1, pd1 = _pts(p12); v2, uv2, lv2, pd2 = _pts(p21)
+    bb1, bb2 = np.array(b1, np.float32), np.array(b2, np.float32)
+    out = np.full(max(len(k1), 1), -1, np.int32)
+    n = lib().orc_search_by_sim3(_p(k1), _p(d1), len(k1), _p(bb1), _p(sf1), _p(k2), _p(d2), len(k2), _p(bb2), _p(sf2),
+                                 _p(v1), _p(uv1), _p(lv1), _p(pd1), _p(v2), _p(uv2), _p(lv2), _p(pd2), th, _p(out))
+    return n, out[:len(k1)].copy()
+
+
+def search_by_projection_kf(cur, pts, cur_has_mp, th, orb_dist, check_ori=True):
+    k, d, b, sf = _tgt(cur); v, uv, lv, pd = _pts(pts)
+    ang = np.ascontiguousarray(pts["angle"], np.float32)
+    out = np.full(max(len(k), 1), -1, np.int32)
+    n = lib().orc_search_by_projection_kf(_p(k), _p(d), len(k), *b, _p(sf), len(v), _p(v), _p(uv), _p(lv), _p(pd), _p(ang), th,
+                                          int(orb_dist), int(check_ori), _p(cur_has_mp), _p(out))
+    return n, out[:len(k)].copy()

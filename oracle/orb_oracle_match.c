@@ -648,3 +648,175 @@ int orc_search_for_triangulation(const orc_keypoint *k1, const uint8_t *d1, int 
     free(matched2);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Projection-guided policies of the back-end.  The pose algebra in front of them (cv::Mat products, cv::norm,
+ * MapPoint::PredictScale) is OpenCV / libm code that stays in the reference's own translation unit; these functions
+ * start where the reference has, for every MapPoint, the flag "passed every geometric test", the projection (u, v[, ur]),
+ * the predicted level and the representative descriptor.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) src/ORBmatcher.cc:1100-1280, from :1168 (radius) to the
+ * selection of bestIdx (:1180-1245).  best_idx[i] = feature of the keyframe the MapPoint is fused into (the caller then
+ * runs Replace / AddObservation / AddMapPoint in order, which does not feed back into the selection), -1 = none.
+ * Returns nFused. */
+int orc_fuse(const orc_keypoint *kk, const uint8_t *dk, const float *ur_k, int nk, float minx, float maxx, float miny,
+             float maxy, const float *scale_factors, const float *inv_level_sigma2, int np, const uint8_t *valid,
+             const float *uv, const float *ur, const int *level, const uint8_t *desc, float th, int fp_mode,
+             int *best_idx) {
+    orc_grid *g = orc_grid_build(kk, nk, minx, maxx, miny, maxy);
+    int *cands = (int *)malloc(sizeof(int) * (size_t)(nk + 1));
+    int nFused = 0;
+    for (int i = 0; i < np; ++i) {
+        best_idx[i] = -1;
+        if (!valid[i]) continue;
+        const float u = uv[2 * i], v = uv[2 * i + 1];
+        const int nPredictedLevel = level[i];
+        const float radius = th * scale_factors[nPredictedLevel];
+        const int nc = orc_grid_query(g, u, v, radius, -1, -1, cands, nk);   /* KeyFrame::GetFeaturesInArea: no level filter */
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int idx = cands[c];
+            const orc_keypoint *kp = &kk[idx];
+            const int kpLevel = kp->octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (ur_k[idx] >= 0) {                                          /* stereo observation: 3-dof chi2 (:1198-1212) */
+                const float ex = u - kp->x, ey = v - kp->y, er = ur[i] - ur_k[idx];
+                const float e2 = fp_mode == ORC_FP_GCC_FMA ? fmaf(er, er, fmaf(ex, ex, ey * ey)) : ex * ex + ey * ey + er * er;
+                if ((double)(e2 * inv_level_sigma2[kpLevel]) > 7.8) continue;
+            } else {
+                const float ex = u - kp->x, ey = v - kp->y;
+                const float e2 = fp_mode == ORC_FP_GCC_FMA ? fmaf(ex, ex, ey * ey) : ex * ex + ey * ey;
+                if ((double)(e2 * inv_level_sigma2[kpLevel]) > 5.99) continue;
+            }
+            const int dist = orc_descriptor_distance(desc + 32 * (size_t)i, dk + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; nFused++; }
+    }
+    free(cands);
+    orc_grid_free(g);
+    return nFused;
+}
+
+/* Shared by Fuse(KF, Scw, ...) :1282-1430 and SearchByProjection(KF, Scw, vpPoints, vpMatched, th) :415-560:
+ * level band [pred - 1, pred], no chi2 gate, bestDist <= TH_LOW.  `taken` (may be NULL) = vpMatched[idx] != NULL,
+ * updated as the reference updates vpMatched (the order of the points matters). */
+static int orc_project_and_pick(const orc_keypoint *kk, const uint8_t *dk, int nk, float minx, float maxx, float miny,
+                                float maxy, const float *scale_factors, int np, const uint8_t *valid, const float *uv,
+                                const int *level, const uint8_t *desc, float th, int init_best, int max_dist,
+                                uint8_t *taken, int *best_idx) {
+    orc_grid *g = orc_grid_build(kk, nk, minx, maxx, miny, maxy);
+    int *cands = (int *)malloc(sizeof(int) * (size_t)(nk + 1));
+    int n = 0;
+    for (int i = 0; i < np; ++i) {
+        best_idx[i] = -1;
+        if (!valid[i]) continue;
+        const int nPredictedLevel = level[i];
+        const float radius = th * scale_factors[nPredictedLevel];
+        const int nc = orc_grid_query(g, uv[2 * i], uv[2 * i + 1], radius, -1, -1, cands, nk);
+        int bestDist = init_best, bestIdx = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int idx = cands[c];
+            if (taken && taken[idx]) continue;
+            const int kpLevel = kk[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int dist = orc_descriptor_distance(desc + 32 * (size_t)i, dk + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= max_dist) {
+            best_idx[i] = bestIdx;
+            if (taken) taken[bestIdx] = 1;
+            n++;
+        }
+    }
+    free(cands);
+    orc_grid_free(g);
+    return n;
+}
+
+/* ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, vpPoints, th, vpReplacePoint) :1282-1430 */
+int orc_fuse_sim3(const orc_keypoint *kk, const uint8_t *dk, int nk, float minx, float maxx, float miny, float maxy,
+                  const float *scale_factors, int np, const uint8_t *valid, const float *uv, const int *level,
+                  const uint8_t *desc, float th, int *best_idx) {
+    return orc_project_and_pick(kk, dk, nk, minx, maxx, miny, maxy, scale_factors, np, valid, uv, level, desc, th, INT_MAX,
+                                TH_LOW, NULL, best_idx);
+}
+
+/* ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, vpPoints, vpMatched, int th) :415-560; matched[nk] in/out */
+int orc_search_by_projection_sim3(const orc_keypoint *kk, const uint8_t *dk, int nk, float minx, float maxx, float miny,
+                                  float maxy, const float *scale_factors, int np, const uint8_t *valid, const float *uv,
+                                  const int *level, const uint8_t *desc, int th, uint8_t *matched, int *best_idx) {
+    return orc_project_and_pick(kk, dk, nk, minx, maxx, miny, maxy, scale_factors, np, valid, uv, level, desc, (float)th, 256,
+                                TH_LOW, matched, best_idx);
+}
+
+/* ORBmatcher::SearchBySim3 :1433-1690 from the two projection loops on: points of KF1 projected into KF2 (valid1 already
+ * includes "has a good MapPoint and !vbAlreadyMatched1"), points of KF2 into KF1, TH_HIGH, then the mutual-agreement
+ * pass.  matches12[n1] = KF2 feature whose MapPoint becomes vpMatches12[i1] (only NEW matches), -1 otherwise. */
+int orc_search_by_sim3(const orc_keypoint *k1, const uint8_t *d1, int n1, const float *bounds1, const float *sf1,
+                       const orc_keypoint *k2, const uint8_t *d2, int n2, const float *bounds2, const float *sf2,
+                       const uint8_t *valid1, const float *uv1in2, const int *level1in2, const uint8_t *mpdesc1,
+                       const uint8_t *valid2, const float *uv2in1, const int *level2in1, const uint8_t *mpdesc2, float th,
+                       int *matches12) {
+    int *m1 = (int *)malloc(sizeof(int) * (size_t)(n1 + 1)), *m2 = (int *)malloc(sizeof(int) * (size_t)(n2 + 1));
+    orc_project_and_pick(k2, d2, n2, bounds2[0], bounds2[1], bounds2[2], bounds2[3], sf2, n1, valid1, uv1in2, level1in2,
+                         mpdesc1, th, INT_MAX, TH_HIGH, NULL, m1);
+    orc_project_and_pick(k1, d1, n1, bounds1[0], bounds1[1], bounds1[2], bounds1[3], sf1, n2, valid2, uv2in1, level2in1,
+                         mpdesc2, th, INT_MAX, TH_HIGH, NULL, m2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; ++i1) {
+        matches12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { matches12[i1] = idx2; nFound++; }
+    }
+    free(m1); free(m2);
+    return nFound;
+}
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) :1873-2020 (relocalisation).
+ * Points = pKF's MapPoints (valid: good, not already found, projection inside the image, distance in range); cur_has_mp[nc]
+ * = CurrentFrame.mvpMapPoints[i2] != NULL, updated; matched_point[nc] = index of the point attached to feature i2, -1. */
+int orc_search_by_projection_kf(const orc_keypoint *kc, const uint8_t *dc, int nc, float minx, float maxx, float miny,
+                                float maxy, const float *scale_factors, int np, const uint8_t *valid, const float *uv,
+                                const int *level, const uint8_t *desc, const float *kf_angle, float th, int orb_dist,
+                                int check_ori, uint8_t *cur_has_mp, int *matched_point) {
+    orc_grid *g = orc_grid_build(kc, nc, minx, maxx, miny, maxy);
+    int *cands = (int *)malloc(sizeof(int) * (size_t)(nc + 1));
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; ++i) { hist[i] = (int *)malloc(sizeof(int) * (size_t)(nc + 1)); hn[i] = 0; }
+    for (int i = 0; i < nc; ++i) matched_point[i] = -1;
+    int nmatches = 0;
+    for (int i = 0; i < np; ++i) {
+        if (!valid[i]) continue;
+        const int nPredictedLevel = level[i];
+        const float radius = th * scale_factors[nPredictedLevel];
+        const int ncand = orc_grid_query(g, uv[2 * i], uv[2 * i + 1], radius, nPredictedLevel - 1, nPredictedLevel + 1, cands, nc);
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < ncand; ++c) {
+            const int i2 = cands[c];
+            if (cur_has_mp[i2]) continue;
+            const int dist = orc_descriptor_distance(desc + 32 * (size_t)i, dc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= orb_dist) {
+            cur_has_mp[bestIdx2] = 1;
+            matched_point[bestIdx2] = i;
+            nmatches++;
+            if (check_ori) bow_rot_bin_push(hist, hn, kf_angle[i], kc[bestIdx2].angle, bestIdx2);
+        }
+    }
+    if (check_ori) {
+        int sizes[HISTO_LENGTH], i1, i2, i3;
+        for (int i = 0; i < HISTO_LENGTH; ++i) sizes[i] = hn[i];
+        orc_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; ++i) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int j = 0; j < hn[i]; ++j) { cur_has_mp[hist[i][j]] = 0; matched_point[hist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
+    free(cands);
+    orc_grid_free(g);
+    return nmatches;
+}

@@ -55,6 +55,17 @@ class KeyFrameView(C.Structure):
                 ("level_sigma2", C.c_void_p)]
 
 
+class ProjectedPoints(C.Structure):
+    _fields_ = [("n", C.c_int32), ("valid", C.c_void_p), ("uv", C.c_void_p), ("u_right", C.c_void_p), ("level", C.c_void_p),
+                ("desc", C.c_void_p), ("angle", C.c_void_p)]
+
+
+class TargetView(C.Structure):
+    _fields_ = [("keys_un", C.c_void_p), ("desc", C.c_void_p), ("u_right", C.c_void_p), ("n", C.c_int32),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("scale_factors", C.c_void_p), ("inv_level_sigma2", C.c_void_p)]
+
+
 class OrbxError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"orbx status {status}: {msg}")
@@ -73,7 +84,8 @@ SYMBOLS = [
     "orbx_grid_create", "orbx_grid_destroy", "orbx_grid_query", "orbx_three_maxima",
     "orbx_search_for_initialization", "orbx_stereo_match", "orbx_search_by_projection_frame",
     "orbx_search_by_projection_mappoints", "orbx_set_input_format", "orbx_search_by_bow_keyframe_frame",
-    "orbx_search_by_bow_keyframes", "orbx_search_for_triangulation",
+    "orbx_search_by_bow_keyframes", "orbx_search_for_triangulation", "orbx_fuse", "orbx_fuse_sim3",
+    "orbx_search_by_projection_sim3", "orbx_search_by_sim3", "orbx_search_by_projection_keyframe",
 ]
 
 _lib = None
@@ -148,6 +160,14 @@ def lib():
     L.orbx_search_for_triangulation.restype = i32
     L.orbx_search_for_triangulation.argtypes = [vp, C.POINTER(KeyFrameView), C.POINTER(KeyFrameView), vp, f32, f32, i32,
                                                 i32, vp, C.POINTER(i32)]
+    PT, TV = C.POINTER(ProjectedPoints), C.POINTER(TargetView)
+    L.orbx_fuse.restype = i32; L.orbx_fuse.argtypes = [vp, TV, PT, f32, vp, C.POINTER(i32)]
+    L.orbx_fuse_sim3.restype = i32; L.orbx_fuse_sim3.argtypes = [vp, TV, PT, f32, vp, C.POINTER(i32)]
+    L.orbx_search_by_projection_sim3.restype = i32
+    L.orbx_search_by_projection_sim3.argtypes = [vp, TV, PT, i32, vp, vp, C.POINTER(i32)]
+    L.orbx_search_by_sim3.restype = i32; L.orbx_search_by_sim3.argtypes = [vp, TV, TV, PT, PT, f32, vp, C.POINTER(i32)]
+    L.orbx_search_by_projection_keyframe.restype = i32
+    L.orbx_search_by_projection_keyframe.argtypes = [vp, TV, PT, f32, i32, i32, vp, vp, C.POINTER(i32)]
     _lib = L
     return L
 

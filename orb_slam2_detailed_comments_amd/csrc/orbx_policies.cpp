@@ -235,3 +235,206 @@ extern "C" orbx_status orbx_search_for_triangulation(orbx_handle *h, const orbx_
     *nmatches_out = nmatches;
     return ORBX_OK;
 }
+
+// ================================================================================================================
+// Projection-guided back-end policies (second half): Fuse (both overloads),
+// SearchByProjection(KeyFrame*, Scw, ...), SearchBySim3, SearchByProjection(Frame&, KeyFrame*, ...).
+// The pose algebra in front of them is cv::Mat / cv::norm / MapPoint::PredictScale code that stays in the maintainer's
+// shim (it IS the reference's code); the entry points start where the reference holds, per MapPoint, the flag "passed every
+// geometric test", the projection, the predicted level and the representative descriptor.
+// GPU: one Hamming matrix (points x features).  Host: GetFeaturesInArea, level band, chi2 gate, first-best selection and
+// the order-dependent bookkeeping, as the reference runs them.
+// ================================================================================================================
+extern "C" orbx_grid *orbx_grid_create(const orbx_keypoint *kps, int n, float min_x, float max_x, float min_y, float max_y);
+extern "C" void orbx_grid_destroy(orbx_grid *g);
+extern "C" int orbx_grid_query(const orbx_grid *g, float x, float y, float r, int min_level, int max_level, int32_t *out, int cap);
+
+namespace {
+const int TH_HIGH_ = 100;
+
+bool target_ok(const orbx_target_view *t) {
+    return t && t->n >= 0 && t->scale_factors && (t->n == 0 || (t->keys_un && t->desc)) && t->max_x > t->min_x && t->max_y > t->min_y;
+}
+bool points_ok(const orbx_projected_points *p) {
+    return p && p->n >= 0 && (p->n == 0 || (p->valid && p->uv && p->level && p->desc));
+}
+
+// distances of every point descriptor to every target descriptor, row-major [np][nk]
+orbx_status point_matrix(orbx_handle *h, const orbx_projected_points *p, const orbx_target_view *t, std::vector<uint16_t> &D) {
+    D.assign((size_t)p->n * t->n, 0);
+    if (p->n == 0 || t->n == 0) return ORBX_OK;
+    return orbx_hamming_matrix(h, p->desc, p->n, t->desc, t->n, D.data());
+}
+
+// level band [pred - 1, pred], no chi2 gate; `taken` as the reference's vpMatched (NULL = not used)
+orbx_status project_and_pick(orbx_handle *h, const orbx_target_view *t, const orbx_projected_points *p, float th, int init_best,
+                             int max_dist, uint8_t *taken, int32_t *best_idx, int *count) {
+    *count = 0;
+    for (int i = 0; i < p->n; ++i) best_idx[i] = -1;
+    if (p->n == 0 || t->n == 0) return ORBX_OK;
+    std::vector<uint16_t> D;
+    orbx_status st = point_matrix(h, p, t, D);
+    if (st != ORBX_OK) return st;
+    orbx_grid *g = orbx_grid_create(t->keys_un, t->n, t->min_x, t->max_x, t->min_y, t->max_y);
+    if (!g) return orbx_fail(ORBX_BAD_ARGUMENT, "bad image bounds");
+    std::vector<int32_t> cands((size_t)t->n);
+    int n = 0;
+    for (int i = 0; i < p->n; ++i) {
+        if (!p->valid[i]) continue;
+        const int pred = p->level[i];
+        const float radius = th * t->scale_factors[pred];
+        const int nc = orbx_grid_query(g, p->uv[2 * i], p->uv[2 * i + 1], radius, -1, -1, cands.data(), t->n);
+        int bestDist = init_best, bestIdx = -1;
+        const uint16_t *row = &D[(size_t)i * t->n];
+        for (int c = 0; c < nc; ++c) {
+            const int idx = cands[c];
+            if (taken && taken[idx]) continue;
+            const int lvl = t->keys_un[idx].octave;
+            if (lvl < pred - 1 || lvl > pred) continue;
+            const int dist = row[idx];
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= max_dist) {
+            best_idx[i] = bestIdx;
+            if (taken) taken[bestIdx] = 1;
+            n++;
+        }
+    }
+    orbx_grid_destroy(g);
+    *count = n;
+    return ORBX_OK;
+}
+}  // namespace
+
+extern "C" orbx_status orbx_fuse(orbx_handle *h, const orbx_target_view *kf, const orbx_projected_points *pts, float th,
+                                 int32_t *best_idx, int *nfused) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!target_ok(kf) || !points_ok(pts) || !best_idx || !nfused || !kf->inv_level_sigma2 || (kf->n > 0 && !kf->u_right) ||
+        (pts->n > 0 && !pts->u_right))
+        return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    *nfused = 0;
+    for (int i = 0; i < pts->n; ++i) best_idx[i] = -1;
+    if (pts->n == 0 || kf->n == 0) return ORBX_OK;
+    const bool fma_mode = orbx_handle_fp_mode(h) == ORBX_FP_GCC_FMA;
+    std::vector<uint16_t> D;
+    orbx_status st = point_matrix(h, pts, kf, D);
+    if (st != ORBX_OK) return st;
+    orbx_grid *g = orbx_grid_create(kf->keys_un, kf->n, kf->min_x, kf->max_x, kf->min_y, kf->max_y);
+    if (!g) return orbx_fail(ORBX_BAD_ARGUMENT, "bad image bounds");
+    std::vector<int32_t> cands((size_t)kf->n);
+    int n = 0;
+    for (int i = 0; i < pts->n; ++i) {
+        if (!pts->valid[i]) continue;
+        const float u = pts->uv[2 * i], v = pts->uv[2 * i + 1];
+        const int pred = pts->level[i];
+        const float radius = th * kf->scale_factors[pred];
+        const int nc = orbx_grid_query(g, u, v, radius, -1, -1, cands.data(), kf->n);
+        int bestDist = 256, bestIdx = -1;
+        const uint16_t *row = &D[(size_t)i * kf->n];
+        for (int c = 0; c < nc; ++c) {
+            const int idx = cands[c];
+            const orbx_keypoint &kp = kf->keys_un[idx];
+            const int lvl = kp.octave;
+            if (lvl < pred - 1 || lvl > pred) continue;
+            if (kf->u_right[idx] >= 0) {       // stereo observation: 3-dof chi2 at 95 % (src/ORBmatcher.cc:1198-1212)
+                const float ex = u - kp.x, ey = v - kp.y, er = pts->u_right[i] - kf->u_right[idx];
+                const float e2 = fma_mode ? std::fmaf(er, er, std::fmaf(ex, ex, ey * ey)) : ex * ex + ey * ey + er * er;
+                if ((double)(e2 * kf->inv_level_sigma2[lvl]) > 7.8) continue;
+            } else {                            // monocular: 2-dof
+                const float ex = u - kp.x, ey = v - kp.y;
+                const float e2 = fma_mode ? std::fmaf(ex, ex, ey * ey) : ex * ex + ey * ey;
+                if ((double)(e2 * kf->inv_level_sigma2[lvl]) > 5.99) continue;
+            }
+            const int dist = row[idx];
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW_) { best_idx[i] = bestIdx; n++; }
+    }
+    orbx_grid_destroy(g);
+    *nfused = n;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_fuse_sim3(orbx_handle *h, const orbx_target_view *kf, const orbx_projected_points *pts, float th,
+                                      int32_t *best_idx, int *nfused) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!target_ok(kf) || !points_ok(pts) || !best_idx || !nfused) return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    return project_and_pick(h, kf, pts, th, INT32_MAX, TH_LOW_, nullptr, best_idx, nfused);
+}
+
+extern "C" orbx_status orbx_search_by_projection_sim3(orbx_handle *h, const orbx_target_view *kf,
+                                                      const orbx_projected_points *pts, int th, uint8_t *matched,
+                                                      int32_t *best_idx, int *nmatches) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!target_ok(kf) || !points_ok(pts) || !best_idx || !nmatches || (kf->n > 0 && !matched)) return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    return project_and_pick(h, kf, pts, (float)th, 256, TH_LOW_, matched, best_idx, nmatches);
+}
+
+extern "C" orbx_status orbx_search_by_sim3(orbx_handle *h, const orbx_target_view *kf1, const orbx_target_view *kf2,
+                                           const orbx_projected_points *pts1_in_2, const orbx_projected_points *pts2_in_1,
+                                           float th, int32_t *matches12, int *nfound) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!target_ok(kf1) || !target_ok(kf2) || !points_ok(pts1_in_2) || !points_ok(pts2_in_1) || !matches12 || !nfound ||
+        pts1_in_2->n != kf1->n || pts2_in_1->n != kf2->n)
+        return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument (one projected point per keyframe feature is expected)");
+    std::vector<int32_t> m1((size_t)kf1->n + 1), m2((size_t)kf2->n + 1);
+    int c1 = 0, c2 = 0;
+    orbx_status st = project_and_pick(h, kf2, pts1_in_2, th, INT32_MAX, TH_HIGH_, nullptr, m1.data(), &c1);
+    if (st != ORBX_OK) return st;
+    st = project_and_pick(h, kf1, pts2_in_1, th, INT32_MAX, TH_HIGH_, nullptr, m2.data(), &c2);
+    if (st != ORBX_OK) return st;
+    int n = 0;
+    for (int i1 = 0; i1 < kf1->n; ++i1) {           // mutual agreement (:1670-1688)
+        matches12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { matches12[i1] = idx2; n++; }
+    }
+    *nfound = n;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_search_by_projection_keyframe(orbx_handle *h, const orbx_target_view *cur,
+                                                          const orbx_projected_points *pts, float th, int orb_dist,
+                                                          int check_orientation, uint8_t *cur_has_map_point,
+                                                          int32_t *matched_point, int *nmatches_out) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!target_ok(cur) || !points_ok(pts) || !matched_point || !nmatches_out || (cur->n > 0 && !cur_has_map_point) ||
+        (check_orientation && pts->n > 0 && !pts->angle))
+        return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    *nmatches_out = 0;
+    for (int i = 0; i < cur->n; ++i) matched_point[i] = -1;
+    if (pts->n == 0 || cur->n == 0) return ORBX_OK;
+    std::vector<uint16_t> D;
+    orbx_status st = point_matrix(h, pts, cur, D);
+    if (st != ORBX_OK) return st;
+    orbx_grid *g = orbx_grid_create(cur->keys_un, cur->n, cur->min_x, cur->max_x, cur->min_y, cur->max_y);
+    if (!g) return orbx_fail(ORBX_BAD_ARGUMENT, "bad image bounds");
+    std::vector<int32_t> cands((size_t)cur->n);
+    RotHist hist;
+    int nmatches = 0;
+    for (int i = 0; i < pts->n; ++i) {
+        if (!pts->valid[i]) continue;
+        const int pred = pts->level[i];
+        const float radius = th * cur->scale_factors[pred];
+        const int nc = orbx_grid_query(g, pts->uv[2 * i], pts->uv[2 * i + 1], radius, pred - 1, pred + 1, cands.data(), cur->n);
+        int bestDist = 256, bestIdx2 = -1;
+        const uint16_t *row = &D[(size_t)i * cur->n];
+        for (int c = 0; c < nc; ++c) {
+            const int i2 = cands[c];
+            if (cur_has_map_point[i2]) continue;
+            const int dist = row[i2];
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= orb_dist) {
+            cur_has_map_point[bestIdx2] = 1;
+            matched_point[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) hist.push(pts->angle[i], cur->keys_un[bestIdx2].angle, bestIdx2);
+        }
+    }
+    if (check_orientation)
+        hist.reject_minor([&](int i2) { cur_has_map_point[i2] = 0; matched_point[i2] = -1; nmatches--; });
+    orbx_grid_destroy(g);
+    *nmatches_out = nmatches;
+    return ORBX_OK;
+}

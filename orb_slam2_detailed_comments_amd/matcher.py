@@ -174,6 +174,80 @@ class ORBmatcher:
                                                     ptr(out), C.byref(n)))
         return n.value, out[:v1.n].copy()
 
+    # ---- projection-guided back-end policies (src/ORBmatcher.cc:1100-1280, 1282-1430, 415-560, 1433-1690, 1873-2020)
+    @staticmethod
+    def _target(t, keep):
+        """t: dict keys_un, desc, bounds (minx, maxx, miny, maxy), scale_factors [, u_right, inv_level_sigma2]"""
+        a = lambda x, ty: np.ascontiguousarray(x, ty)
+        keys, desc, sf = a(t["keys_un"], _capi.KP_DTYPE), a(t["desc"], np.uint8), a(t["scale_factors"], np.float32)
+        keep += [keys, desc, sf]
+        v = _capi.TargetView()
+        v.keys_un, v.desc, v.n, v.scale_factors = keys.ctypes.data, desc.ctypes.data, len(keys), sf.ctypes.data
+        v.min_x, v.max_x, v.min_y, v.max_y = [float(b) for b in t["bounds"]]
+        for name in ("u_right", "inv_level_sigma2"):
+            if t.get(name) is not None:
+                arr = a(t[name], np.float32); keep.append(arr); setattr(v, name, arr.ctypes.data)
+        return v
+
+    @staticmethod
+    def _points(p, keep):
+        """p: dict valid, uv [n,2], level, desc [, u_right, angle]"""
+        a = lambda x, ty: np.ascontiguousarray(x, ty)
+        valid, uv, level, desc = a(p["valid"], np.uint8), a(p["uv"], np.float32), a(p["level"], np.int32), a(p["desc"], np.uint8)
+        keep += [valid, uv, level, desc]
+        v = _capi.ProjectedPoints()
+        v.n, v.valid, v.uv, v.level, v.desc = len(valid), valid.ctypes.data, uv.ctypes.data, level.ctypes.data, desc.ctypes.data
+        for name in ("u_right", "angle"):
+            if p.get(name) is not None:
+                arr = a(p[name], np.float32); keep.append(arr); setattr(v, name, arr.ctypes.data)
+        return v
+
+    def Fuse(self, kf, pts, th=3.0):
+        """Fuse(KeyFrame*, vpMapPoints, th), selection part.  Returns (nFused, best_idx[n_points])."""
+        import ctypes as C
+        keep = []; tv, pv = self._target(kf, keep), self._points(pts, keep)
+        out = np.full(max(pv.n, 1), -1, np.int32); n = C.c_int(0)
+        check(self._L.orbx_fuse(self._ex.handle, C.byref(tv), C.byref(pv), float(th), ptr(out), C.byref(n)))
+        return n.value, out[:pv.n].copy()
+
+    def FuseSim3(self, kf, pts, th):
+        """Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint), selection part."""
+        import ctypes as C
+        keep = []; tv, pv = self._target(kf, keep), self._points(pts, keep)
+        out = np.full(max(pv.n, 1), -1, np.int32); n = C.c_int(0)
+        check(self._L.orbx_fuse_sim3(self._ex.handle, C.byref(tv), C.byref(pv), float(th), ptr(out), C.byref(n)))
+        return n.value, out[:pv.n].copy()
+
+    def SearchByProjectionSim3(self, kf, pts, matched, th):
+        """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th); `matched` (uint8 per feature) is updated in place."""
+        import ctypes as C
+        keep = []; tv, pv = self._target(kf, keep), self._points(pts, keep)
+        assert matched.dtype == np.uint8 and matched.flags.c_contiguous and len(matched) == tv.n
+        out = np.full(max(pv.n, 1), -1, np.int32); n = C.c_int(0)
+        check(self._L.orbx_search_by_projection_sim3(self._ex.handle, C.byref(tv), C.byref(pv), int(th), ptr(matched), ptr(out),
+                                                     C.byref(n)))
+        return n.value, out[:pv.n].copy()
+
+    def SearchBySim3(self, kf1, kf2, pts1_in_2, pts2_in_1, th):
+        import ctypes as C
+        keep = []
+        t1, t2 = self._target(kf1, keep), self._target(kf2, keep)
+        p12, p21 = self._points(pts1_in_2, keep), self._points(pts2_in_1, keep)
+        out = np.full(max(t1.n, 1), -1, np.int32); n = C.c_int(0)
+        check(self._L.orbx_search_by_sim3(self._ex.handle, C.byref(t1), C.byref(t2), C.byref(p12), C.byref(p21), float(th),
+                                          ptr(out), C.byref(n)))
+        return n.value, out[:t1.n].copy()
+
+    def SearchByProjectionKeyFrame(self, cur, pts, cur_has_map_point, th, ORBdist):
+        """SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist); cur_has_map_point updated in place."""
+        import ctypes as C
+        keep = []; tv, pv = self._target(cur, keep), self._points(pts, keep)
+        assert cur_has_map_point.dtype == np.uint8 and len(cur_has_map_point) == tv.n
+        out = np.full(max(tv.n, 1), -1, np.int32); n = C.c_int(0)
+        check(self._L.orbx_search_by_projection_keyframe(self._ex.handle, C.byref(tv), C.byref(pv), float(th), int(ORBdist),
+                                                         int(self.mbCheckOrientation), ptr(cur_has_map_point), ptr(out), C.byref(n)))
+        return n.value, out[:tv.n].copy()
+
     # ---- ComputeThreeMaxima (src/ORBmatcher.cc:2026-2068): 30 numbers, host side
     @staticmethod
     def ComputeThreeMaxima(sizes):
