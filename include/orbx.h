@@ -290,6 +290,37 @@ orbx_status orbx_search_by_projection_keyframe(orbx_handle *h, const orbx_target
                                                float th, int orb_dist, int check_orientation, uint8_t *cur_has_map_point,
                                                int32_t *matched_point, int *nmatches);
 
+/* ---- DBoW2 transform: Frame::ComputeBoW (src/Frame.cc:750-765) =
+ * TemplatedVocabulary<FORB>::transform(features, BowVector&, FeatureVector&, 4)
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1136-1216, 1240-1285; FORB::distance FORB.cpp:81-101). */
+typedef struct orbx_vocabulary_view {   /* m_nodes flattened; node 0 is the root */
+    int32_t n_nodes, k, L;
+    int32_t weighting;               /* DBoW2::WeightingType: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY */
+    int32_t scoring;                 /* DBoW2::ScoringType: 0 L1_NORM, 1 L2_NORM, 2 CHI_SQUARE, 3 KL, 4 BHATTACHARYYA, 5 DOT_PRODUCT */
+    const int32_t *child_begin;      /* n_nodes + 1 offsets into child_ids: Node::children in vector order */
+    const uint32_t *child_ids;       /* every child id is greater than its parent's (true of every DBoW2-built tree) */
+    const uint8_t *desc;             /* Node::descriptor, n_nodes x 32 (the root's row is not read) */
+    const double *weight;            /* Node::weight */
+    const uint32_t *word_id;         /* Node::word_id (meaningful for leaves) */
+} orbx_vocabulary_view;
+typedef struct orbx_vocabulary orbx_vocabulary;
+/* copies the tree to the handle's device; the vocabulary can then be used with any handle on that device */
+orbx_status orbx_vocabulary_create(orbx_handle *h, const orbx_vocabulary_view *view, orbx_vocabulary **out);
+void orbx_vocabulary_destroy(orbx_vocabulary *voc);
+/* per descriptor: transform(feature, word_id, weight, &nid, levelsup).  Host buffers. */
+orbx_status orbx_bow_transform(orbx_handle *h, const orbx_vocabulary *voc, const uint8_t *desc, int n, int levelsup,
+                               uint32_t *word_id, double *weight, uint32_t *node_id);
+/* batched, device buffers (descriptors as orbx_extract_batch_device leaves them): d_leaf_node[f][i] = leaf reached by
+ * descriptor i of frame f (word id / weight = tables of the view), d_node_id[f][i] = node at depth L - levelsup */
+orbx_status orbx_bow_transform_device(orbx_handle *h, const orbx_vocabulary *voc, int nframes, const uint8_t *d_desc,
+                                      const int32_t *d_counts, int64_t desc_frame_stride, int max_n, int levelsup,
+                                      uint32_t *d_leaf_node, uint32_t *d_node_id, int out_stride);
+/* the BowVector and FeatureVector transform() builds from the per-descriptor results, flattened in map order (bow_word
+ * ascending with bow_value; fv_node ascending, fv_begin[n_fv_nodes + 1], fv_index = an orbx_featvec_view).  Capacities: n. */
+orbx_status orbx_bow_vectors(const orbx_vocabulary *voc, const uint32_t *word_id, const double *weight,
+                             const uint32_t *node_id, int n, uint32_t *bow_word, double *bow_value, int *n_bow,
+                             uint32_t *fv_node, int32_t *fv_begin, uint32_t *fv_index, int *n_fv_nodes);
+
 /* ---- stream / timing plumbing ------------------------------------------------------------ */
 void *orbx_get_stream(orbx_handle *h);            /* hipStream_t */
 orbx_status orbx_set_stream(orbx_handle *h, void *hip_stream); /* NULL restores the private stream */

@@ -164,6 +164,14 @@ int orc_search_by_projection_kf(const orc_keypoint *kc, const uint8_t *dc, int n
                                 const int *level, const uint8_t *desc, const float *kf_angle, float th, int orb_dist,
                                 int check_ori, uint8_t *cur_has_mp, int *matched_point);
 
+/* ---- DBoW2 TemplatedVocabulary<FORB>::transform on a flattened tree */
+void orc_bow_transform(int n_nodes, int L, const int *child_begin, const uint32_t *child_ids, const uint8_t *node_desc,
+                       const double *node_weight, const uint32_t *node_word, const uint8_t *desc, int n, int levelsup,
+                       uint32_t *word_id, double *weight, uint32_t *node_id);
+int orc_bow_vectors(int weighting, int scoring, const uint32_t *word_id, const double *weight, const uint32_t *node_id,
+                    int n, uint32_t *bow_word, double *bow_value, int *n_bow, uint32_t *fv_node, int *fv_begin,
+                    uint32_t *fv_index, int *n_fv_nodes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,6 +102,10 @@ def lib():
         L.orc_search_by_sim3.argtypes = [vp_, vp_, ci, vp_, vp_] * 2 + [vp_] * 8 + [cf, vp_]
         L.orc_search_by_projection_kf.restype = ci
         L.orc_search_by_projection_kf.argtypes = [vp_, vp_, ci, cf, cf, cf, cf, vp_, ci, vp_, vp_, vp_, vp_, vp_, cf, ci, ci, vp_, vp_]
+        L.orc_bow_transform.restype = None
+        L.orc_bow_transform.argtypes = [ci, ci] + [vp_] * 6 + [ci, ci] + [vp_] * 3
+        L.orc_bow_vectors.restype = ci
+        L.orc_bow_vectors.argtypes = [ci, ci, vp_, vp_, vp_, ci, vp_, vp_, vp_, vp_, vp_, vp_, vp_]
         L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
@@ -411,3 +415,22 @@ def search_by_projection_kf(cur, pts, cur_has_mp, th, orb_dist, check_ori=True):
     n = lib().orc_search_by_projection_kf(_p(k), _p(d), len(k), *b, _p(sf), len(v), _p(v), _p(uv), _p(lv), _p(pd), _p(ang), th,
                                           int(orb_dist), int(check_ori), _p(cur_has_mp), _p(out))
     return n, out[:len(k)].copy()
+
+
+def bow_transform(voc, desc, levelsup=4):
+    """voc: dict n_nodes, L, child_begin, child_ids, desc, weight, word_id (+ weighting, scoring).  Per-descriptor results
+    and the flattened BowVector / FeatureVector: (word_id, weight, node_id, (bow_word, bow_value), (fv_node, fv_begin, fv_index))"""
+    d = np.ascontiguousarray(desc, np.uint8); n = len(d)
+    cb = np.ascontiguousarray(voc["child_begin"], np.int32); ci_ = np.ascontiguousarray(voc["child_ids"], np.uint32)
+    nd = np.ascontiguousarray(voc["desc"], np.uint8); nw = np.ascontiguousarray(voc["weight"], np.float64)
+    nwid = np.ascontiguousarray(voc["word_id"], np.uint32)
+    wid = np.zeros(max(n, 1), np.uint32); w = np.zeros(max(n, 1), np.float64); nid = np.zeros(max(n, 1), np.uint32)
+    lib().orc_bow_transform(int(voc["n_nodes"]), int(voc["L"]), _p(cb), _p(ci_), _p(nd), _p(nw), _p(nwid), _p(d), n, levelsup,
+                            _p(wid), _p(w), _p(nid))
+    bw = np.zeros(max(n, 1), np.uint32); bv = np.zeros(max(n, 1), np.float64)
+    fn = np.zeros(max(n, 1), np.uint32); fb = np.zeros(n + 2, np.int32); fi = np.zeros(max(n, 1), np.uint32)
+    nb, nn = C.c_int(0), C.c_int(0)
+    lib().orc_bow_vectors(int(voc.get("weighting", 0)), int(voc.get("scoring", 0)), _p(wid), _p(w), _p(nid), n, _p(bw), _p(bv),
+                          C.byref(nb), _p(fn), _p(fb), _p(fi), C.byref(nn))
+    return (wid[:n].copy(), w[:n].copy(), nid[:n].copy(), (bw[:nb.value].copy(), bv[:nb.value].copy()),
+            (fn[:nn.value].copy(), fb[:nn.value + 1].copy(), fi[:fb[nn.value]].copy()))

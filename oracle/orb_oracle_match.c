@@ -820,3 +820,82 @@ int orc_search_by_projection_kf(const orc_keypoint *kc, const uint8_t *dc, int n
     orc_grid_free(g);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * DBoW2: TemplatedVocabulary<FORB>::transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1240-1285 per feature,
+ * :1136-1216 for the BowVector / FeatureVector; BowVector.cpp:40-95; FORB::distance FORB.cpp:81-101).
+ * The tree is passed flattened (CSR of Node::children).  When the descent ends above level L - levelsup the reference
+ * leaves *nid unassigned; 0 is returned here.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_bow_transform(int n_nodes, int L, const int *child_begin, const uint32_t *child_ids, const uint8_t *node_desc,
+                       const double *node_weight, const uint32_t *node_word, const uint8_t *desc, int n, int levelsup,
+                       uint32_t *word_id, double *weight, uint32_t *node_id) {
+    (void)n_nodes;
+    const int nid_level = L - levelsup;
+    for (int i = 0; i < n; ++i) {
+        uint32_t final_id = 0, nid = 0;
+        int current_level = 0;
+        while (child_begin[final_id] != child_begin[final_id + 1]) {           /* do { } while (!isLeaf) on a non-empty tree */
+            ++current_level;
+            const int cb = child_begin[final_id], ce = child_begin[final_id + 1];
+            uint32_t best = child_ids[cb];
+            double best_d = (double)orc_descriptor_distance(desc + 32 * (size_t)i, node_desc + 32 * (size_t)best);
+            for (int c = cb + 1; c < ce; ++c) {
+                const double d = (double)orc_descriptor_distance(desc + 32 * (size_t)i, node_desc + 32 * (size_t)child_ids[c]);
+                if (d < best_d) { best_d = d; best = child_ids[c]; }
+            }
+            final_id = best;
+            if (current_level == nid_level) nid = final_id;
+        }
+        word_id[i] = node_word[final_id];
+        weight[i] = node_weight[final_id];
+        node_id[i] = nid;
+    }
+}
+
+/* literal std::map emulation with sorted arrays + insertion, in feature order */
+int orc_bow_vectors(int weighting, int scoring, const uint32_t *word_id, const double *weight, const uint32_t *node_id,
+                    int n, uint32_t *bow_word, double *bow_value, int *n_bow, uint32_t *fv_node, int *fv_begin,
+                    uint32_t *fv_index, int *n_fv_nodes) {
+    int nb = 0, nn = 0;
+    int *cnt = (int *)calloc((size_t)n + 1, sizeof(int));
+    uint32_t *tmp_idx = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1) * (size_t)(n > 0 ? 1 : 1));
+    /* FeatureVector: per node a growing list; emulate with (node, feature) pairs kept sorted by node, stable */
+    uint32_t *pn = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1)), *pf = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1));
+    int np = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!(weight[i] > 0)) continue;
+        /* v.addWeight / addIfNotExist */
+        int lo = 0;
+        while (lo < nb && bow_word[lo] < word_id[i]) ++lo;                       /* lower_bound */
+        if (lo < nb && bow_word[lo] == word_id[i]) {
+            if (weighting == 0 || weighting == 1) bow_value[lo] += weight[i];
+        } else {
+            for (int j = nb; j > lo; --j) { bow_word[j] = bow_word[j - 1]; bow_value[j] = bow_value[j - 1]; }
+            bow_word[lo] = word_id[i]; bow_value[lo] = weight[i]; ++nb;
+        }
+        /* fv.addFeature(nid, i_feature) */
+        int p = np;
+        while (p > 0 && pn[p - 1] > node_id[i]) { pn[p] = pn[p - 1]; pf[p] = pf[p - 1]; --p; }
+        pn[p] = node_id[i]; pf[p] = (uint32_t)i; ++np;
+    }
+    const int norm = scoring == 1 ? 2 : scoring == 5 ? 0 : 1;                     /* ScoringObject::mustNormalize */
+    if ((weighting == 0 || weighting == 1) && nb > 0 && norm == 0) {
+        const double nd = (double)nb;
+        for (int i = 0; i < nb; ++i) bow_value[i] /= nd;
+    }
+    if (norm) {
+        double s = 0.0;
+        if (norm == 1) for (int i = 0; i < nb; ++i) s += fabs(bow_value[i]);
+        else { for (int i = 0; i < nb; ++i) s += bow_value[i] * bow_value[i]; s = sqrt(s); }
+        if (s > 0.0) for (int i = 0; i < nb; ++i) bow_value[i] /= s;
+    }
+    fv_begin[0] = 0;
+    for (int i = 0; i < np; ++i) {
+        if (i == 0 || pn[i] != pn[i - 1]) { fv_node[nn] = pn[i]; ++nn; fv_begin[nn] = fv_begin[nn - 1]; }
+        fv_index[fv_begin[nn]++] = pf[i];
+    }
+    *n_bow = nb; *n_fv_nodes = nn;
+    free(cnt); free(tmp_idx); free(pn); free(pf);
+    return nb;
+}

@@ -7,3 +7,4 @@ from ._capi import KP_DTYPE, OrbxError, LIB_PATH  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import ORBmatcher  # noqa: F401
 from .frame import Frame  # noqa: F401
+from .vocabulary import ORBVocabulary  # noqa: F401

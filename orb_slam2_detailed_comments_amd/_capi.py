@@ -66,6 +66,12 @@ class TargetView(C.Structure):
                 ("scale_factors", C.c_void_p), ("inv_level_sigma2", C.c_void_p)]
 
 
+class VocabularyView(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("k", C.c_int32), ("L", C.c_int32), ("weighting", C.c_int32), ("scoring", C.c_int32),
+                ("child_begin", C.c_void_p), ("child_ids", C.c_void_p), ("desc", C.c_void_p), ("weight", C.c_void_p),
+                ("word_id", C.c_void_p)]
+
+
 class OrbxError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"orbx status {status}: {msg}")
@@ -86,6 +92,7 @@ SYMBOLS = [
     "orbx_search_by_projection_mappoints", "orbx_set_input_format", "orbx_search_by_bow_keyframe_frame",
     "orbx_search_by_bow_keyframes", "orbx_search_for_triangulation", "orbx_fuse", "orbx_fuse_sim3",
     "orbx_search_by_projection_sim3", "orbx_search_by_sim3", "orbx_search_by_projection_keyframe",
+    "orbx_vocabulary_create", "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_bow_transform_device", "orbx_bow_vectors",
 ]
 
 _lib = None
@@ -168,6 +175,13 @@ def lib():
     L.orbx_search_by_sim3.restype = i32; L.orbx_search_by_sim3.argtypes = [vp, TV, TV, PT, PT, f32, vp, C.POINTER(i32)]
     L.orbx_search_by_projection_keyframe.restype = i32
     L.orbx_search_by_projection_keyframe.argtypes = [vp, TV, PT, f32, i32, i32, vp, vp, C.POINTER(i32)]
+    L.orbx_vocabulary_create.restype = i32; L.orbx_vocabulary_create.argtypes = [vp, C.POINTER(VocabularyView), C.POINTER(vp)]
+    L.orbx_vocabulary_destroy.restype = None; L.orbx_vocabulary_destroy.argtypes = [vp]
+    L.orbx_bow_transform.restype = i32; L.orbx_bow_transform.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    L.orbx_bow_transform_device.restype = i32
+    L.orbx_bow_transform_device.argtypes = [vp, vp, i32, vp, vp, i64, i32, i32, vp, vp, i32]
+    L.orbx_bow_vectors.restype = i32
+    L.orbx_bow_vectors.argtypes = [vp, vp, vp, vp, i32, vp, vp, C.POINTER(i32), vp, vp, vp, C.POINTER(i32)]
     _lib = L
     return L
 

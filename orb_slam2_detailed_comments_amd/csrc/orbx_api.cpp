@@ -1071,3 +1071,151 @@ extern "C" orbx_status orbx_search_by_projection_mappoints(orbx_handle *h, const
     *nmatches_out = nmatches;
     return ORBX_OK;
 }
+
+// ---------------------------------------------------------------- (f)3: DBoW2 transform (Frame::ComputeBoW, src/Frame.cc:750-765)
+// TemplatedVocabulary<FORB>::transform(features, BowVector&, FeatureVector&, levelsup)
+// (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1136-1216): the tree descent of every descriptor runs on the GPU
+// (k_bow_transform); word id / weight look-ups and the two std::map accumulations (double precision, feature order) on the host.
+struct orbx_vocabulary {
+    int dev = 0;
+    int n_nodes = 0, k = 0, L = 0, weighting = 0, scoring = 0;
+    std::vector<int32_t> child_begin;
+    std::vector<uint32_t> child_ids, word_id;
+    std::vector<double> weight;
+    int *d_child_begin = nullptr;
+    uint32_t *d_child_ids = nullptr;
+    uint8_t *d_desc = nullptr;
+};
+
+extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v) {
+    if (!v) return;
+    hipSetDevice(v->dev);
+    hipFree(v->d_child_begin); hipFree(v->d_child_ids); hipFree(v->d_desc);
+    delete v;
+}
+
+extern "C" orbx_status orbx_vocabulary_create(orbx_handle *h, const orbx_vocabulary_view *view, orbx_vocabulary **out) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (!view || !out || view->n_nodes < 1 || !view->child_begin || !view->desc || !view->weight || !view->word_id ||
+        view->L < 0 || view->weighting < 0 || view->weighting > 3 || view->scoring < 0 || view->scoring > 5)
+        return fail(ORBX_BAD_ARGUMENT, "bad vocabulary view");
+    const int n = view->n_nodes;
+    if (view->child_begin[0] != 0) return fail(ORBX_BAD_ARGUMENT, "child_begin[0] != 0");
+    for (int i = 0; i < n; ++i) {
+        if (view->child_begin[i + 1] < view->child_begin[i]) return fail(ORBX_BAD_ARGUMENT, "child_begin not monotonic");
+        for (int c = view->child_begin[i]; c < view->child_begin[i + 1]; ++c) {
+            if (!view->child_ids) return fail(ORBX_BAD_ARGUMENT, "null child_ids");
+            // DBoW2 appends children after their parent (create / load*): ids grow down the tree, so the descent terminates
+            if (view->child_ids[c] <= (uint32_t)i || view->child_ids[c] >= (uint32_t)n)
+                return fail(ORBX_BAD_ARGUMENT, "child id out of range or not greater than its parent");
+        }
+        if (view->child_begin[i + 1] - view->child_begin[i] > 65535) return fail(ORBX_BAD_ARGUMENT, "too many children");
+    }
+    HIPCHK(hipSetDevice(h->dev));
+    orbx_vocabulary *v = new orbx_vocabulary();
+    v->dev = h->dev; v->n_nodes = n; v->k = view->k; v->L = view->L; v->weighting = view->weighting; v->scoring = view->scoring;
+    const int nchild = view->child_begin[n];
+    v->child_begin.assign(view->child_begin, view->child_begin + n + 1);
+    v->child_ids.assign(view->child_ids, view->child_ids + nchild);
+    v->word_id.assign(view->word_id, view->word_id + n);
+    v->weight.assign(view->weight, view->weight + n);
+    hipError_t e = hipMalloc(&v->d_child_begin, (size_t)(n + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&v->d_child_ids, std::max<size_t>(1, nchild) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&v->d_desc, (size_t)n * 32);
+    if (e == hipSuccess) e = hipMemcpy(v->d_child_begin, view->child_begin, (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nchild > 0) e = hipMemcpy(v->d_child_ids, view->child_ids, (size_t)nchild * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_desc, view->desc, (size_t)n * 32, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { orbx_vocabulary_destroy(v); return fail(ORBX_HIP_ERROR, hipGetErrorString(e)); }
+    *out = v;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_bow_transform_device(orbx_handle *h, const orbx_vocabulary *voc, int nframes, const uint8_t *d_desc,
+                                                 const int32_t *d_counts, int64_t desc_frame_stride, int max_n, int levelsup,
+                                                 uint32_t *d_leaf_node, uint32_t *d_node_id, int out_stride) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (!voc || nframes <= 0 || !d_desc || !d_counts || max_n <= 0 || !d_leaf_node || !d_node_id || out_stride < max_n)
+        return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    if (voc->dev != h->dev) return fail(ORBX_BAD_ARGUMENT, "vocabulary lives on another device");
+    HIPCHK(hipSetDevice(h->dev));
+    { ProfScope ps(h, ORBX_K_MISC);
+      orbx_launch_bow_transform(h->stream, nframes, max_n, voc->d_child_begin, voc->d_child_ids, voc->d_desc, voc->n_nodes, voc->L,
+                                d_desc, d_counts, desc_frame_stride, levelsup, d_leaf_node, d_node_id, out_stride); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_bow_transform(orbx_handle *h, const orbx_vocabulary *voc, const uint8_t *desc, int n, int levelsup,
+                                          uint32_t *word_id, double *weight, uint32_t *node_id) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (!voc || n < 0 || (n > 0 && (!desc || !word_id || !weight || !node_id))) return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    if (n == 0) return ORBX_OK;
+    HIPCHK(hipSetDevice(h->dev));
+    orbx_status st = scratch_reserve(h, pad256((size_t)n * 32) + pad256(sizeof(int)) + 2 * pad256((size_t)n * sizeof(uint32_t)));
+    if (st != ORBX_OK) return st;
+    uint8_t *dd = scratch_take<uint8_t>(h, (size_t)n * 32);
+    int *dn = scratch_take<int>(h, 1);
+    uint32_t *dleaf = scratch_take<uint32_t>(h, (size_t)n), *dnid = scratch_take<uint32_t>(h, (size_t)n);
+    HIPCHK(hipMemcpyAsync(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dn, &n, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    st = orbx_bow_transform_device(h, voc, 1, dd, dn, (int64_t)n * 32, n, levelsup, dleaf, dnid, n);
+    if (st != ORBX_OK) return st;
+    std::vector<uint32_t> leaf((size_t)n);
+    HIPCHK(hipMemcpyAsync(leaf.data(), dleaf, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(node_id, dnid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i) {
+        if (leaf[i] >= (uint32_t)voc->n_nodes) return fail(ORBX_HIP_ERROR, "transform returned an invalid node");
+        word_id[i] = voc->word_id[leaf[i]];
+        weight[i] = voc->weight[leaf[i]];
+    }
+    return ORBX_OK;
+}
+
+// BowVector / FeatureVector exactly as TemplatedVocabulary::transform fills them (:1150-1216, BowVector.cpp:40-95):
+// addWeight / addIfNotExist in feature order, division by the vector size when the scoring does not normalise, L1 / L2
+// normalisation in ascending word order.  Outputs are the maps flattened in key order.
+extern "C" orbx_status orbx_bow_vectors(const orbx_vocabulary *voc, const uint32_t *word_id, const double *weight,
+                                        const uint32_t *node_id, int n, uint32_t *bow_word, double *bow_value, int *n_bow,
+                                        uint32_t *fv_node, int32_t *fv_begin, uint32_t *fv_index, int *n_fv_nodes) {
+    if (!voc || n < 0 || !n_bow || !n_fv_nodes || !fv_begin || (n > 0 && (!word_id || !weight || !node_id || !bow_word || !bow_value ||
+                                                                           !fv_node || !fv_index)))
+        return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    // mustNormalize (ScoringObject.cpp): L1_NORM, CHI_SQUARE, KL, BHATTACHARYYA -> L1; L2_NORM -> L2; DOT_PRODUCT -> none
+    const int norm = voc->scoring == 1 ? 2 : voc->scoring == 5 ? 0 : 1;
+    const bool tf = voc->weighting == 0 || voc->weighting == 1;   // TF_IDF, TF: addWeight; IDF, BINARY: addIfNotExist
+    std::vector<int> order;
+    order.reserve((size_t)n);
+    for (int i = 0; i < n; ++i) if (weight[i] > 0) order.push_back(i);          // w > 0: not a stopped word
+    std::vector<int> byword(order), bynode(order);
+    std::stable_sort(byword.begin(), byword.end(), [&](int a, int b) { return word_id[a] < word_id[b]; });
+    std::stable_sort(bynode.begin(), bynode.end(), [&](int a, int b) { return node_id[a] < node_id[b]; });
+    int nb = 0;
+    for (size_t i = 0; i < byword.size();) {
+        size_t j = i;
+        double acc = weight[byword[i]];
+        for (j = i + 1; j < byword.size() && word_id[byword[j]] == word_id[byword[i]]; ++j)
+            if (tf) acc += weight[byword[j]];                                      // feature order inside one word (stable sort)
+        bow_word[nb] = word_id[byword[i]]; bow_value[nb] = acc; ++nb;
+        i = j;
+    }
+    if (tf && nb > 0 && norm == 0) { const double nd = (double)nb; for (int i = 0; i < nb; ++i) bow_value[i] /= nd; }
+    if (norm != 0) {
+        double s = 0.0;
+        if (norm == 1) for (int i = 0; i < nb; ++i) s += fabs(bow_value[i]);
+        else { for (int i = 0; i < nb; ++i) s += bow_value[i] * bow_value[i]; s = sqrt(s); }
+        if (s > 0.0) for (int i = 0; i < nb; ++i) bow_value[i] /= s;
+    }
+    *n_bow = nb;
+    int nn = 0, pos = 0;
+    fv_begin[0] = 0;
+    for (size_t i = 0; i < bynode.size();) {
+        size_t j = i;
+        for (; j < bynode.size() && node_id[bynode[j]] == node_id[bynode[i]]; ++j) fv_index[pos++] = (uint32_t)bynode[j];
+        fv_node[nn] = node_id[bynode[i]]; ++nn; fv_begin[nn] = pos;
+        i = j;
+    }
+    *n_fv_nodes = nn;
+    return ORBX_OK;
+}

@@ -1811,6 +1811,67 @@ __global__ __launch_bounds__(256) void k_stereo(OrbxStereoGeom sg, const orbx_ke
 }
 
 // small helper: zero per-batch counters / status
+// ------------------------------------------------------------------------------------------------
+// K9: DBoW2 TemplatedVocabulary<FORB>::transform(feature, word_id, weight, nid, levelsup)
+// (reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1240-1285, FORB::distance FORB.cpp:81-101; caller
+// Frame::ComputeBoW src/Frame.cc:750-765 with levelsup = 4).  16 lanes per descriptor: lane c takes child c of the current
+// node (k <= 20 in every loadable vocabulary: one or two rounds), XOR + popcount over the 8 dwords, then a rotate-reduce
+// inside the 16-lane DPP row on the key (distance << 16 | position) -- the minimum is the FIRST closest child, as the
+// reference's strict '<' scan picks it.  Outputs the leaf node and the node at depth L - levelsup; word id and weight are
+// table look-ups the host does in double precision.
+// ------------------------------------------------------------------------------------------------
+struct DVoc {
+    const int *child_begin;       // n_nodes + 1 offsets into child_ids (Node::children in vector order)
+    const uint32_t *child_ids;
+    const uint8_t *desc;          // n_nodes x 32
+    int n_nodes, L;
+};
+__device__ __forceinline__ uint32_t orbx_row16_min(uint32_t v) {   // all-reduce min inside each row of 16 lanes
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false));   // row_ror:1
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false));   // row_ror:2
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));   // row_ror:4
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));   // row_ror:8
+    return v;
+}
+__global__ __launch_bounds__(256) void k_bow_transform(DVoc voc, const uint8_t *__restrict__ desc,
+                                                       const int *__restrict__ counts, long long frame_stride, int levelsup,
+                                                       uint32_t *__restrict__ out_leaf, uint32_t *__restrict__ out_nid,
+                                                       int out_stride) {
+    const int sub = threadIdx.x & 15;
+    const int feat = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int f = blockIdx.y;
+    const int n = counts[f];
+    // inactive groups keep walking a dummy descriptor: the DPP reduction wants whole rows executing together
+    const bool live = feat < n;
+    const uint4 *q = (const uint4 *)(desc + (long long)f * frame_stride + (long long)(live ? feat : 0) * 32);
+    const uint4 qa = n > 0 ? q[0] : make_uint4(0, 0, 0, 0), qb = n > 0 ? q[1] : make_uint4(0, 0, 0, 0);
+    const int nid_level = voc.L - levelsup;
+    uint32_t node = 0, nid = 0;
+    for (int level = 1; level <= 64; ++level) {   // child ids exceed their parent's (checked on the host): terminates
+        const int cb = voc.child_begin[node], ce = voc.child_begin[node + 1];
+        if (cb == ce) break;                      // leaf
+        uint32_t best = 0xffffffffu;
+        for (int c0 = cb; c0 < ce; c0 += 16) {
+            const int c = c0 + sub;
+            uint32_t key = 0xffffffffu;
+            if (c < ce) {
+                const uint4 *t = (const uint4 *)(voc.desc + (long long)voc.child_ids[c] * 32);
+                const uint4 ta = t[0], tb = t[1];
+                const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                                   __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+                key = (d << 16) | (uint32_t)(c - cb);
+            }
+            best = min(best, orbx_row16_min(key));
+        }
+        node = voc.child_ids[cb + (int)(best & 0xffffu)];
+        if (level == nid_level) nid = node;
+    }
+    if (live && sub == 0) {
+        out_leaf[(long long)f * out_stride + feat] = node;
+        out_nid[(long long)f * out_stride + feat] = nid;
+    }
+}
+
 __global__ void k_clear(int *a, int na, int *b, int nb, int *c, int nc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < na) a[i] = 0;
@@ -1903,6 +1964,15 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
     const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256;
     hipLaunchKernelGGL(k_fast_rows, dim3(B, (ngroups + FR_GPW - 1) / FR_GPW), dim3(64), smem, s, g, cells, groups, pyr, cand,
                        cell_count, max_ch, lcap, ngroups, dbg_stop);
+}
+void orbx_launch_bow_transform(hipStream_t s, int B, int max_n, const int *child_begin, const uint32_t *child_ids,
+                               const uint8_t *node_desc, int n_nodes, int L, const uint8_t *desc, const int *counts,
+                               long long frame_stride, int levelsup, uint32_t *out_leaf, uint32_t *out_nid, int out_stride) {
+    if (B <= 0 || max_n <= 0) return;
+    DVoc v;
+    v.child_begin = child_begin; v.child_ids = child_ids; v.desc = node_desc; v.n_nodes = n_nodes; v.L = L;
+    hipLaunchKernelGGL(k_bow_transform, dim3((max_n + 15) / 16, B), dim3(256), 0, s, v, desc, counts, frame_stride, levelsup,
+                       out_leaf, out_nid, out_stride);
 }
 void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
                           const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,

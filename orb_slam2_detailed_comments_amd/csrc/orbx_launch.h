@@ -16,6 +16,9 @@ void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cell
                       int *cell_count, int max_cw, int max_ch, int cell_begin, int cell_end);
 void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *groups,
                            int ngroups, const uint8_t *pyr, uint2 *cand, int *cell_count, int max_ch, int lcap, int dbg_stop);
+void orbx_launch_bow_transform(hipStream_t s, int B, int max_n, const int *child_begin, const uint32_t *child_ids,
+                               const uint8_t *node_desc, int n_nodes, int L, const uint8_t *desc, const int *counts,
+                               long long frame_stride, int levelsup, uint32_t *out_leaf, uint32_t *out_nid, int out_stride);
 void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
                           const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,
                           int *status, uint16_t *knode_glob, int ncap, int lds_keys);
