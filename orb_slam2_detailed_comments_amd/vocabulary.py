@@ -53,7 +53,11 @@ class ORBVocabulary:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orbx_vocabulary_destroy(self._h); self._h = None
+            try:
+                lib().orbx_vocabulary_destroy(self._h)
+            except Exception:   # interpreter shutdown: module globals are already gone
+                pass
+            self._h = None
 
     def transform_features(self, desc, levelsup=4):
         """per descriptor (word_id, weight, node_id)"""
