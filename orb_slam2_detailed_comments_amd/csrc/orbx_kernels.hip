@@ -827,7 +827,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
                                                           const OrbxFastGroup *__restrict__ groups,
                                                           const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
                                                           int *__restrict__ cell_count, int rows, int lcap, int ngroups,
-                                                          int dbg_stop) {
+                                                          int gpw, int dbg_stop) {
     // dbg_stop (ORBX_FAST_STOP, timing experiments only; results are wrong unless 0): 1 = after staging, 2 = after the
     // pre-test, 3 = after the ring test, 4 = before NMS
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
@@ -839,8 +839,8 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     const int f = blockIdx.x;   // frame fastest: all groups of one frame share one XCD's L2
     // FR_GPW groups per wave, one after the other: the next group's tile is fetched into registers while this one
     // is processed, so the global-load latency is never waited for
-    const int g0 = blockIdx.y * FR_GPW;
-    const int ng = min(FR_GPW, ngroups - g0);
+    const int g0 = blockIdx.y * gpw;
+    const int ng = min(gpw, ngroups - g0);
     const int rq = (lane * 49) >> 10, dq = lane - 21 * rq;   // staging: 3 rows x 21 dwords per step
     uint32_t tv[14];
     OrbxFastGroup grp_n = groups[g0];
@@ -1958,6 +1958,8 @@ __global__ void k_clear(int *a, int na, int *b, int nb, int *c, int nc) {
 // launch wrappers (called from orbx_api.cpp)
 // ------------------------------------------------------------------------------------------------
 #include "orbx_launch.h"
+#include <string>
+#include <cstdio>
 
 hipError_t orbx_upload_pattern() {
     signed char t[64 * 16];
@@ -2008,7 +2010,11 @@ void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, con
             dim3 grid(bx, (row_blocks + nit - 1) / nit, B);
             hipLaunchKernelGGL(k_pyr_resize_flat, grid, dim3(256), 0, s, g, level, taps, pyr, nit);
         } else {
-            const int rpw = par > 0 ? par : 16;
+            // destination rows per wave: 16 when the launch still has >= 4096 waves, fewer for small batches (the rows of a
+            // wave are a serial chain of load -> evaluate -> store steps)
+            int rpw = par > 0 ? par : 16;
+            if (par <= 0)
+                while (rpw > 2 && (long long)((L.pw + 255) / 256) * ((L.ph + rpw - 1) / rpw) * B < 4096) rpw >>= 1;
             dim3 grid((L.pw + 255) / 256, (L.ph + 4 * rpw - 1) / (4 * rpw), B);
             hipLaunchKernelGGL(k_pyr_resize_rows, grid, dim3(64, 4), 0, s, g, level, taps, pyr, rpw);
         }
@@ -2037,8 +2043,11 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
     if (ngroups <= 0) return;
     lcap = (max(lcap, 64) + 1) & ~1;
     const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256;
-    hipLaunchKernelGGL(k_fast_rows, dim3(B, (ngroups + FR_GPW - 1) / FR_GPW), dim3(64), smem, s, g, cells, groups, pyr, cand,
-                       cell_count, max_ch, lcap, ngroups, dbg_stop);
+    // groups per wave: FR_GPW when the launch has waves to spare (the second group's tile is prefetched while the first
+    // is processed); one per wave for small batches, where the serial length of a wave is what the caller waits for
+    const int gpw = (long long)B * ngroups >= 16384 ? FR_GPW : 1;
+    hipLaunchKernelGGL(k_fast_rows, dim3(B, (ngroups + gpw - 1) / gpw), dim3(64), smem, s, g, cells, groups, pyr, cand,
+                       cell_count, max_ch, lcap, ngroups, gpw, dbg_stop);
 }
 void orbx_launch_bow_transform(hipStream_t s, int B, int max_n, const int *child_begin, const uint32_t *child_ids,
                                const uint8_t *node_desc, int n_nodes, int L, const uint8_t *desc, const int *counts,
@@ -2093,3 +2102,4 @@ void orbx_launch_stereo(hipStream_t s, const OrbxStereoGeom &sg, const orbx_keyp
     hipLaunchKernelGGL(k_stereo, dim3((nL + 3) / 4), dim3(256), 0, s, sg, kL, dL, nL, kR, dR, nR, pyrL, pyrR, uRight,
                        depth, sad);
 }
+
