@@ -158,6 +158,15 @@ orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int frame_left, 
                               const uint8_t *dr, int nr, float mb, float mbf, float *u_right, float *depth,
                               int *nmatches);
 
+/* Batched, device-resident form: pair p = frame p of the last orbx_extract_batch_device of `hl` (left eyes) and of `hr`
+ * (right eyes); d_k* / d_d* / d_n* are the device buffers those calls filled, `cap` records apart.  Outputs (device):
+ * u_right / depth [npairs][cap], nmatches [npairs].  The median cut of :1160-1175 runs on the device too.  Asynchronous on
+ * hl's stream. */
+orbx_status orbx_stereo_match_batch_device(orbx_handle *hl, orbx_handle *hr, int npairs, const orbx_keypoint *d_kl,
+                                           const uint8_t *d_dl, const int32_t *d_nl, const orbx_keypoint *d_kr,
+                                           const uint8_t *d_dr, const int32_t *d_nr, int cap, float mb, float mbf,
+                                           float *d_u_right, float *d_depth, int32_t *d_nmatches);
+
 /* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (src/ORBmatcher.cc:1702-1871;
  * caller Tracking::TrackWithMotionModel, src/Tracking.cc:1430,1445).  The Frame / MapPoint fields the policy reads are
  * passed as arrays.  CurrentFrame.mvpMapPoints is all-NULL on entry (src/Tracking.cc:1420 fills it); the result is

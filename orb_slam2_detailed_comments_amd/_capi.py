@@ -92,7 +92,7 @@ SYMBOLS = [
     "orbx_search_by_projection_mappoints", "orbx_set_input_format", "orbx_search_by_bow_keyframe_frame",
     "orbx_search_by_bow_keyframes", "orbx_search_for_triangulation", "orbx_fuse", "orbx_fuse_sim3",
     "orbx_search_by_projection_sim3", "orbx_search_by_sim3", "orbx_search_by_projection_keyframe",
-    "orbx_vocabulary_create", "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_bow_transform_device", "orbx_bow_vectors",
+    "orbx_stereo_match_batch_device", "orbx_vocabulary_create", "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_bow_transform_device", "orbx_bow_vectors",
 ]
 
 _lib = None
@@ -182,6 +182,8 @@ def lib():
     L.orbx_bow_transform_device.argtypes = [vp, vp, i32, vp, vp, i64, i32, i32, vp, vp, i32]
     L.orbx_bow_vectors.restype = i32
     L.orbx_bow_vectors.argtypes = [vp, vp, vp, vp, i32, vp, vp, C.POINTER(i32), vp, vp, vp, C.POINTER(i32)]
+    L.orbx_stereo_match_batch_device.restype = i32
+    L.orbx_stereo_match_batch_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp]
     _lib = L
     return L
 

@@ -904,6 +904,45 @@ extern "C" orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int f
     return ORBX_OK;
 }
 
+// Batched, device-resident Frame::ComputeStereoMatches: pair p = frame p of the last extraction of `hl` (left) and of
+// `hr` (right); keypoints / descriptors / counts are the device buffers orbx_extract_batch_device filled (stride `cap`
+// records per frame).  The median cut (:1160-1175) also runs on the device (k_stereo_cut), nothing returns to the host.
+extern "C" orbx_status orbx_stereo_match_batch_device(orbx_handle *hl, orbx_handle *hr, int npairs, const orbx_keypoint *d_kl,
+                                                      const uint8_t *d_dl, const int32_t *d_nl, const orbx_keypoint *d_kr,
+                                                      const uint8_t *d_dr, const int32_t *d_nr, int cap, float mb, float mbf,
+                                                      float *d_u_right, float *d_depth, int32_t *d_nmatches) {
+    if (!hl || !hr || hl->host_only || hr->host_only) return fail(ORBX_BAD_ARGUMENT, "two device handles are required");
+    if (npairs <= 0 || cap <= 0 || cap > 65535 || !d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_u_right || !d_depth ||
+        !d_nmatches || !(mb > 0.f))
+        return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    orbx_status st = check_level(hl, npairs - 1, 0);
+    if (st != ORBX_OK) return st;
+    st = check_level(hr, npairs - 1, 0);
+    if (st != ORBX_OK) return st;
+    if (hl->dev != hr->dev || hl->geom.width != hr->geom.width || hl->geom.height != hr->geom.height ||
+        hl->p.nlevels != hr->p.nlevels || hl->p.scale_factor != hr->p.scale_factor)
+        return fail(ORBX_BAD_ARGUMENT, "left and right extractor must share device, image size and pyramid parameters");
+    HIPCHK(hipSetDevice(hl->dev));
+    if (hr->stream != hl->stream) HIPCHK(hipStreamSynchronize(hr->stream));   // the right pyramids are read from the left stream
+    OrbxStereoGeom sg;
+    memset(&sg, 0, sizeof(sg));
+    sg.nlevels = hl->p.nlevels; sg.nrows0 = hl->geom.lv[0].ph; sg.mb = mb; sg.mbf = mbf;
+    for (int l = 0; l < sg.nlevels; ++l) {
+        sg.scale[l] = hl->tab.scale[l]; sg.inv_scale[l] = hl->tab.inv_scale[l];
+        sg.pw[l] = hl->geom.lv[l].pw; sg.ph[l] = hl->geom.lv[l].ph; sg.pitch[l] = hl->geom.lv[l].pitch;
+        sg.off[l] = hl->geom.lv[l].off;
+    }
+    st = scratch_reserve(hl, pad256((size_t)npairs * cap * sizeof(int)));
+    if (st != ORBX_OK) return st;
+    int *dsad = scratch_take<int>(hl, (size_t)npairs * cap);
+    { ProfScope ps(hl, ORBX_K_MATCH);
+      orbx_launch_stereo_batch(hl->stream, sg, npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, hl->d_pyr, hr->d_pyr,
+                               (long long)hl->geom.pyr_bytes, d_u_right, d_depth, dsad, d_nmatches); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
+    return ORBX_OK;
+}
+
 // ---------------------------------------------------------------- a14: SearchByProjection(Frame&, const Frame&, th, bMono)
 // (src/ORBmatcher.cc:1702-1871; caller TrackWithMotionModel src/Tracking.cc:1430,1445).  GPU: Hamming matrix between
 // the representative descriptors of the last frame's MapPoints and the current frame's descriptors.  Host: projection

@@ -1794,13 +1794,13 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t *__restric
 //           parabola (:1121-1129) uses the same single-rounded float operations as the reference.
 // The final median cut (:1160-1175) is a sort over <= N integers and stays on the host (orbx_api.cpp).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stereo(OrbxStereoGeom sg, const orbx_keypoint *__restrict__ kL,
-                                                const uint8_t *__restrict__ dL, int nL,
-                                                const orbx_keypoint *__restrict__ kR,
-                                                const uint8_t *__restrict__ dR, int nR,
-                                                const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
-                                                float *__restrict__ uRight, float *__restrict__ depth,
-                                                int *__restrict__ sad) {
+__device__ __forceinline__ void orbx_stereo_body(const OrbxStereoGeom &sg, const orbx_keypoint *__restrict__ kL,
+                                                 const uint8_t *__restrict__ dL, int nL,
+                                                 const orbx_keypoint *__restrict__ kR,
+                                                 const uint8_t *__restrict__ dR, int nR,
+                                                 const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
+                                                 float *__restrict__ uRight, float *__restrict__ depth,
+                                                 int *__restrict__ sad) {
     const int lane = threadIdx.x & 63;
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (iL >= nL) return;
@@ -1883,6 +1883,80 @@ __global__ __launch_bounds__(256) void k_stereo(OrbxStereoGeom sg, const orbx_ke
         uRight[iL] = bestuR;
         sad[iL] = bestDistS;
     }
+}
+
+__global__ __launch_bounds__(256) void k_stereo(OrbxStereoGeom sg, const orbx_keypoint *__restrict__ kL,
+                                                const uint8_t *__restrict__ dL, int nL,
+                                                const orbx_keypoint *__restrict__ kR,
+                                                const uint8_t *__restrict__ dR, int nR,
+                                                const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
+                                                float *__restrict__ uRight, float *__restrict__ depth,
+                                                int *__restrict__ sad) {
+    orbx_stereo_body(sg, kL, dL, nL, kR, dR, nR, pyrL, pyrR, uRight, depth, sad);
+}
+// batched: blockIdx.y = stereo pair; keypoints / descriptors / results of pair p at p * cap, pyramids at p * pyr_bytes
+__global__ __launch_bounds__(256) void k_stereo_batch(OrbxStereoGeom sg, const orbx_keypoint *__restrict__ kL,
+                                                      const uint8_t *__restrict__ dL, const int *__restrict__ nL,
+                                                      const orbx_keypoint *__restrict__ kR,
+                                                      const uint8_t *__restrict__ dR, const int *__restrict__ nR, int cap,
+                                                      const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
+                                                      long long pyr_bytes, float *__restrict__ uRight,
+                                                      float *__restrict__ depth, int *__restrict__ sad) {
+    const long long p = blockIdx.y;
+    orbx_stereo_body(sg, kL + p * cap, dL + p * cap * 32, min(nL[p], cap), kR + p * cap, dR + p * cap * 32, min(nR[p], cap),
+                     pyrL + p * pyr_bytes, pyrR + p * pyr_bytes, uRight + p * cap, depth + p * cap, sad + p * cap);
+}
+// Median cut of Frame::ComputeStereoMatches (src/Frame.cc:1160-1175) on the device, one workgroup per pair: the reference
+// sorts (SAD, index) and drops everything with SAD >= 1.5f * 1.4f * median, median = element size/2 of the sorted list.
+// Only the VALUE of that element matters: two 256-bin histogram passes over the 16-bit SAD (<= 121 * 510) select it.
+__global__ __launch_bounds__(256) void k_stereo_cut(const int *__restrict__ nL, int cap, const int *__restrict__ sad,
+                                                    float *__restrict__ uRight, float *__restrict__ depth,
+                                                    int *__restrict__ nmatches) {
+    __shared__ int hist[256];
+    __shared__ int s_sel, s_rank, s_kept;
+    const long long p = blockIdx.x;
+    const int n = min(nL[p], cap), t = threadIdx.x;
+    const int *sd = sad + p * cap;
+    float *ur = uRight + p * cap, *dp = depth + p * cap;
+    hist[t] = 0;
+    if (t == 0) s_kept = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 256) { const int v = sd[i]; if (v >= 0) atomicAdd(&hist[(v >> 8) & 255], 1); }
+    __syncthreads();
+    if (t == 0) {
+        int cnt = 0;
+        for (int b = 0; b < 256; ++b) cnt += hist[b];
+        s_sel = -1; s_rank = 0;
+        if (cnt > 0) {
+            int k = cnt / 2, acc = 0;
+            for (int b = 0; b < 256; ++b) { if (k < acc + hist[b]) { s_sel = b; s_rank = k - acc; break; } acc += hist[b]; }
+        }
+        s_kept = cnt;
+    }
+    __syncthreads();
+    const int hi = s_sel, rank = s_rank;
+    if (hi < 0) { if (t == 0) nmatches[p] = 0; return; }
+    __syncthreads();
+    hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 256) { const int v = sd[i]; if (v >= 0 && ((v >> 8) & 255) == hi) atomicAdd(&hist[v & 255], 1); }
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0, lo = 0;
+        for (int b = 0; b < 256; ++b) { if (rank < acc + hist[b]) { lo = b; break; } acc += hist[b]; }
+        s_sel = (hi << 8) | lo;
+    }
+    __syncthreads();
+    const float median = (float)s_sel;
+    const float thDist = 1.5f * 1.4f * median;
+    int dropped = 0;
+    for (int i = t; i < n; i += 256) {
+        const int v = sd[i];
+        if (v >= 0 && (float)v >= thDist) { ur[i] = -1.0f; dp[i] = -1.0f; ++dropped; }
+    }
+    if (dropped) atomicSub(&s_kept, dropped);
+    __syncthreads();
+    if (t == 0) nmatches[p] = s_kept;
 }
 
 // small helper: zero per-batch counters / status
@@ -2095,6 +2169,15 @@ void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const u
     hipLaunchKernelGGL(k_hamming_matrix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q, nq, t, nt, dist);
 }
 
+void orbx_launch_stereo_batch(hipStream_t s, const OrbxStereoGeom &sg, int npairs, int cap, const orbx_keypoint *kL,
+                              const uint8_t *dL, const int *nL, const orbx_keypoint *kR, const uint8_t *dR, const int *nR,
+                              const uint8_t *pyrL, const uint8_t *pyrR, long long pyr_bytes, float *uRight, float *depth,
+                              int *sad, int *nmatches) {
+    if (npairs <= 0 || cap <= 0) return;
+    hipLaunchKernelGGL(k_stereo_batch, dim3((cap + 3) / 4, npairs), dim3(256), 0, s, sg, kL, dL, nL, kR, dR, nR, cap, pyrL, pyrR,
+                       pyr_bytes, uRight, depth, sad);
+    hipLaunchKernelGGL(k_stereo_cut, dim3(npairs), dim3(256), 0, s, nL, cap, sad, uRight, depth, nmatches);
+}
 void orbx_launch_stereo(hipStream_t s, const OrbxStereoGeom &sg, const orbx_keypoint *kL, const uint8_t *dL, int nL,
                         const orbx_keypoint *kR, const uint8_t *dR, int nR, const uint8_t *pyrL, const uint8_t *pyrR,
                         float *uRight, float *depth, int *sad) {

@@ -32,6 +32,10 @@ void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, 
 size_t orbx_match_workspace_bytes(int npairs, int out_stride);
 void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *dist);
 
+void orbx_launch_stereo_batch(hipStream_t s, const OrbxStereoGeom &sg, int npairs, int cap, const orbx_keypoint *kL,
+                              const uint8_t *dL, const int *nL, const orbx_keypoint *kR, const uint8_t *dR, const int *nR,
+                              const uint8_t *pyrL, const uint8_t *pyrR, long long pyr_bytes, float *uRight, float *depth,
+                              int *sad, int *nmatches);
 void orbx_launch_stereo(hipStream_t s, const OrbxStereoGeom &sg, const orbx_keypoint *kL, const uint8_t *dL, int nL,
                         const orbx_keypoint *kR, const uint8_t *dR, int nR, const uint8_t *pyrL, const uint8_t *pyrR,
                         float *uRight, float *depth, int *sad);

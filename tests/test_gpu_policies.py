@@ -135,3 +135,39 @@ def test_search_by_projection_local_map_points(th, ratio, stereo):
                                                    in_view, proj, level, view_cos, d0, mp_obs, th, ratio)
     assert n == on and np.array_equal(assigned, oassigned)
     assert n > 30
+
+
+def test_compute_stereo_matches_batched_device_path():
+    """Batched, device-resident ComputeStereoMatches (extraction of both eyes + stereo match + median cut without leaving
+    the GPU) against the oracle, pair by pair."""
+    import torch
+    from orb_slam2_detailed_comments_amd import _capi
+    w, h, nf, B, mb, mbf = 752, 480, 1200, 3, 0.11, 47.9
+    pairs = [synth.stereo_pair(w, h, stream_id=60 + i) for i in range(B)]
+    dev = torch.device("cuda", 0)
+    exL, exR = ORBextractor(nf, max_batch=B), ORBextractor(nf, max_batch=B)
+    cap = exL.max_keypoints(w, h)
+    bufs = {}
+    for name, ex, imgs in (("L", exL, [p[0] for p in pairs]), ("R", exR, [p[1] for p in pairs])):
+        d = dict(img=torch.from_numpy(np.stack(imgs)).to(dev), kps=torch.zeros((B, cap * 28), dtype=torch.uint8, device=dev),
+                 desc=torch.zeros((B, cap * 32), dtype=torch.uint8, device=dev), cnt=torch.zeros(B, dtype=torch.int32, device=dev),
+                 st=torch.zeros(B, dtype=torch.int32, device=dev))
+        ex.extract_batch_device(d["img"], B, w, h, w, w * h, d["kps"], d["desc"], d["cnt"], d["st"], cap)
+        bufs[name] = d
+    ur = torch.zeros((B, cap), dtype=torch.float32, device=dev); dep = torch.zeros_like(ur)
+    nm = torch.zeros(B, dtype=torch.int32, device=dev)
+    L = _capi.lib()
+    _capi.check(L.orbx_stereo_match_batch_device(exL.handle, exR.handle, B, _capi.ptr(bufs["L"]["kps"]), _capi.ptr(bufs["L"]["desc"]),
+                                                 _capi.ptr(bufs["L"]["cnt"]), _capi.ptr(bufs["R"]["kps"]), _capi.ptr(bufs["R"]["desc"]),
+                                                 _capi.ptr(bufs["R"]["cnt"]), cap, mb, mbf, _capi.ptr(ur), _capi.ptr(dep), _capi.ptr(nm)))
+    exL.synchronize()
+    for p in range(B):
+        nl, nr = int(bufs["L"]["cnt"][p]), int(bufs["R"]["cnt"][p])
+        kL = np.frombuffer(bufs["L"]["kps"][p].cpu().numpy().tobytes(), _capi.KP_DTYPE)[:nl]
+        kR = np.frombuffer(bufs["R"]["kps"][p].cpu().numpy().tobytes(), _capi.KP_DTYPE)[:nr]
+        dL = bufs["L"]["desc"][p].cpu().numpy().reshape(-1, 32)[:nl]; dR = bufs["R"]["desc"][p].cpu().numpy().reshape(-1, 32)[:nr]
+        pyrL = [exL.pyramid_level(l, p) for l in range(8)]; pyrR = [exR.pyramid_level(l, p) for l in range(8)]
+        on, ou, od = oracle.stereo_matches(kL, dL, kR, dR, exL.GetScaleFactors(), exL.GetInverseScaleFactors(), pyrL, pyrR, mb, mbf)
+        assert int(nm[p]) == on and on > 20
+        assert np.array_equal(ur[p, :nl].cpu().numpy().view(np.uint32), ou.view(np.uint32))
+        assert np.array_equal(dep[p, :nl].cpu().numpy().view(np.uint32), od.view(np.uint32))
