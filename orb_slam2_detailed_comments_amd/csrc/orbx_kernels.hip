@@ -1800,7 +1800,8 @@ __device__ __forceinline__ void orbx_stereo_body(const OrbxStereoGeom &sg, const
                                                  const uint8_t *__restrict__ dR, int nR,
                                                  const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
                                                  float *__restrict__ uRight, float *__restrict__ depth,
-                                                 int *__restrict__ sad) {
+                                                 int *__restrict__ sad, const int *__restrict__ row_begin,
+                                                 const uint16_t *__restrict__ row_items) {
     const int lane = threadIdx.x & 63;
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (iL >= nL) return;
@@ -1816,6 +1817,23 @@ __device__ __forceinline__ void orbx_stereo_body(const OrbxStereoGeom &sg, const
     const uint4 *qp = (const uint4 *)(dL + (long long)iL * 32);
     const uint4 qa = qp[0], qb = qp[1];
     uint32_t best = 0xffffffffu;
+    if (row_begin) {
+        // vRowIndices[vL] of the reference (:926-942), built on the device by k_stereo_rows: only the right keypoints whose
+        // row band covers this row are visited (their order does not matter: ties go to the smallest index, as the
+        // reference's strict '<' over ascending iR resolves them)
+        for (int j = row_begin[row] + lane; j < row_begin[row + 1]; j += 64) {
+            const int iR = row_items[j];
+            const orbx_keypoint kr = kR[iR];
+            const bool cand = (int)(kr.octave >= levelL - 1) & (int)(kr.octave <= levelL + 1) & (int)(kr.x >= minU) & (int)(kr.x <= maxU);
+            if (cand) {
+                const uint4 *tp = (const uint4 *)(dR + (long long)iR * 32);
+                const uint4 ta = tp[0], tb = tp[1];
+                const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                                   __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+                if (d < 100u) best = min(best, (d << 16) | (uint32_t)iR);
+            }
+        }
+    } else
     for (int iR = lane; iR < nR; iR += 64) {
         const orbx_keypoint kr = kR[iR];
         const float r = 2.0f * sg.scale[kr.octave];
@@ -1892,7 +1910,7 @@ __global__ __launch_bounds__(256) void k_stereo(OrbxStereoGeom sg, const orbx_ke
                                                 const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
                                                 float *__restrict__ uRight, float *__restrict__ depth,
                                                 int *__restrict__ sad) {
-    orbx_stereo_body(sg, kL, dL, nL, kR, dR, nR, pyrL, pyrR, uRight, depth, sad);
+    orbx_stereo_body(sg, kL, dL, nL, kR, dR, nR, pyrL, pyrR, uRight, depth, sad, nullptr, nullptr);
 }
 // batched: blockIdx.y = stereo pair; keypoints / descriptors / results of pair p at p * cap, pyramids at p * pyr_bytes
 __global__ __launch_bounds__(256) void k_stereo_batch(OrbxStereoGeom sg, const orbx_keypoint *__restrict__ kL,
@@ -1901,10 +1919,60 @@ __global__ __launch_bounds__(256) void k_stereo_batch(OrbxStereoGeom sg, const o
                                                       const uint8_t *__restrict__ dR, const int *__restrict__ nR, int cap,
                                                       const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
                                                       long long pyr_bytes, float *__restrict__ uRight,
-                                                      float *__restrict__ depth, int *__restrict__ sad) {
+                                                      float *__restrict__ depth, int *__restrict__ sad,
+                                                      const int *__restrict__ row_begin, const uint16_t *__restrict__ row_items,
+                                                      int items_per_pair) {
     const long long p = blockIdx.y;
     orbx_stereo_body(sg, kL + p * cap, dL + p * cap * 32, min(nL[p], cap), kR + p * cap, dR + p * cap * 32, min(nR[p], cap),
-                     pyrL + p * pyr_bytes, pyrR + p * pyr_bytes, uRight + p * cap, depth + p * cap, sad + p * cap);
+                     pyrL + p * pyr_bytes, pyrR + p * pyr_bytes, uRight + p * cap, depth + p * cap, sad + p * cap,
+                     row_begin ? row_begin + p * (sg.nrows0 + 1) : nullptr, row_items ? row_items + p * items_per_pair : nullptr);
+}
+// vRowIndices of Frame::ComputeStereoMatches (src/Frame.cc:926-942) for one stereo pair per workgroup: right keypoint iR is
+// listed under every row of [floor(y - r), ceil(y + r)], r = 2 * mvScaleFactors[octave] (rows outside the image are clamped
+// away: the reference indexes out of bounds there).  Histogram, scan and fill all in LDS; rows <= ST_MAX_ROWS.
+#define ST_MAX_ROWS 4096
+__global__ __launch_bounds__(1024) void k_stereo_rows(OrbxStereoGeom sg, const orbx_keypoint *__restrict__ kR,
+                                                      const int *__restrict__ nR, int cap, int *__restrict__ row_begin,
+                                                      uint16_t *__restrict__ row_items, int items_per_pair) {
+    __shared__ int s_cnt[ST_MAX_ROWS + 1];
+    __shared__ int s_part[1024];
+    const long long p = blockIdx.x;
+    const int t = threadIdx.x, n = min(nR[p], cap), rows = sg.nrows0;
+    const orbx_keypoint *k = kR + p * cap;
+    for (int i = t; i <= rows; i += 1024) s_cnt[i] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        const float r = 2.0f * sg.scale[k[i].octave];
+        const int maxr = min((int)ceilf(k[i].y + r), rows - 1), minr = max((int)floorf(k[i].y - r), 0);
+        for (int y = minr; y <= maxr; ++y) atomicAdd(&s_cnt[y], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the rows: each thread owns a contiguous chunk
+    const int chunk = (rows + 1023) / 1024, r0 = t * chunk, r1 = min(r0 + chunk, rows);
+    int sum = 0;
+    for (int y = r0; y < r1; ++y) sum += s_cnt[y];
+    s_part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = t >= o ? s_part[t - o] : 0;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    int run = s_part[t] - sum;
+    int *rb = row_begin + p * (rows + 1);
+    for (int y = r0; y < r1; ++y) { const int c = s_cnt[y]; s_cnt[y] = run; rb[y] = run; run += c; }
+    if (t == 1023) rb[rows] = s_part[1023];
+    __syncthreads();
+    uint16_t *items = row_items + p * items_per_pair;
+    for (int i = t; i < n; i += 1024) {
+        const float r = 2.0f * sg.scale[k[i].octave];
+        const int maxr = min((int)ceilf(k[i].y + r), rows - 1), minr = max((int)floorf(k[i].y - r), 0);
+        for (int y = minr; y <= maxr; ++y) {
+            const int pos = atomicAdd(&s_cnt[y], 1);
+            if (pos < items_per_pair) items[pos] = (uint16_t)i;
+        }
+    }
 }
 // Median cut of Frame::ComputeStereoMatches (src/Frame.cc:1160-1175) on the device, one workgroup per pair: the reference
 // sorts (SAD, index) and drops everything with SAD >= 1.5f * 1.4f * median, median = element size/2 of the sorted list.
@@ -2169,13 +2237,21 @@ void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const u
     hipLaunchKernelGGL(k_hamming_matrix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q, nq, t, nt, dist);
 }
 
+int orbx_stereo_items_per_pair(const OrbxStereoGeom &sg, int cap) {
+    float smax = 1.f;
+    for (int l = 0; l < sg.nlevels; ++l) smax = sg.scale[l] > smax ? sg.scale[l] : smax;
+    return cap * (2 * (int)ceilf(2.0f * smax) + 3);
+}
 void orbx_launch_stereo_batch(hipStream_t s, const OrbxStereoGeom &sg, int npairs, int cap, const orbx_keypoint *kL,
                               const uint8_t *dL, const int *nL, const orbx_keypoint *kR, const uint8_t *dR, const int *nR,
                               const uint8_t *pyrL, const uint8_t *pyrR, long long pyr_bytes, float *uRight, float *depth,
-                              int *sad, int *nmatches) {
+                              int *sad, int *nmatches, int *row_begin, uint16_t *row_items) {
     if (npairs <= 0 || cap <= 0) return;
+    const int ipp = orbx_stereo_items_per_pair(sg, cap);
+    const bool table = row_begin && row_items && sg.nrows0 <= ST_MAX_ROWS;
+    if (table) hipLaunchKernelGGL(k_stereo_rows, dim3(npairs), dim3(1024), 0, s, sg, kR, nR, cap, row_begin, row_items, ipp);
     hipLaunchKernelGGL(k_stereo_batch, dim3((cap + 3) / 4, npairs), dim3(256), 0, s, sg, kL, dL, nL, kR, dR, nR, cap, pyrL, pyrR,
-                       pyr_bytes, uRight, depth, sad);
+                       pyr_bytes, uRight, depth, sad, table ? row_begin : nullptr, table ? row_items : nullptr, ipp);
     hipLaunchKernelGGL(k_stereo_cut, dim3(npairs), dim3(256), 0, s, nL, cap, sad, uRight, depth, nmatches);
 }
 void orbx_launch_stereo(hipStream_t s, const OrbxStereoGeom &sg, const orbx_keypoint *kL, const uint8_t *dL, int nL,
