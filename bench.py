@@ -3,7 +3,10 @@
 
 A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
   K0..K6 extraction of `--batch` frames (per GPU) + K7 brute-force Hamming match of frame t vs t-1
-  (+ for N > 1 one RCCL all-gather of the per-frame keypoint records).
+  (+ for N > 1 one RCCL gather of the per-frame keypoint records).
+Consecutive steps run on `--streams` pipelines (one handle + HIP stream each) round-robin, so the tail of step i overlaps the
+head of step i+1; every step still does all of its work, and frame 0 of a step is matched against the last frame of the
+step before it (an event links the pipelines).
 Weak scaling: every rank owns its own batch; no collective on the data path.
 """
 import argparse
@@ -92,9 +95,10 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
-    ap.add_argument("--streams", type=int, default=1,
-                    help="independent extract+match pipelines per GPU, used round-robin (3 adds ~10 %% throughput but "
-                         "overlapping kernels blur the per-kernel timing; default 1 keeps the roofline accounting clean)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="extract+match pipelines per GPU (handle + HIP stream each), used round-robin over the steps: the "
+                         "latency-bound tail of one step (quadtree, small pyramid levels) overlaps the issue-bound kernels of "
+                         "the next (+12 %% at 3).  --streams 1 gives un-overlapped per-kernel durations (DESIGN.md section 6 table)")
     ap.add_argument("--gather", default="gather", choices=("gather", "all_gather"),
                     help="collective for the per-frame keypoint records: to rank 0 (default) or to every rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -235,6 +239,7 @@ def main():
                          "end_to_end_GBs": round(total_ab * fps / world / 1e9, 2),
                          "end_to_end_frac": round(total_ab * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_step": {k: round(v[0] / 2, 4) for k, v in prof.items()},
+            "kernel_ms_overlapped": NS > 1,   # with several pipelines the per-kernel durations include time shared with other kernels
         }
         if not args.no_cpu_baseline:
             cfps, nsample = cpu_baseline(frames, NF)
