@@ -40,7 +40,6 @@ struct orbx_handle {
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     OrbxCell *d_cells = nullptr;
     OrbxFastGroup *d_groups = nullptr;
-    int fast_impl = 1;      // 1 = k_fast_rows (default), 0 = k_fast_cells (ORBX_FAST_IMPL=cells, kept for A/B runs)
     bool resize_legacy = false;   // ORBX_RESIZE_IMPL=legacy: k_pyr_resize for every level (A/B runs)
     int fast_stop = 0;      // ORBX_FAST_STOP: timing experiments only
     int fast_lcap = 640;    // LDS work-list entries of k_fast_rows (ORBX_FAST_LCAP; tests shrink it to force the flush paths)
@@ -210,7 +209,6 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
         HIPCHK(hipMemcpy(h->d_cells, g.cells.data(), g.cells.size() * sizeof(OrbxCell), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_groups, g.fast_groups.data(), g.fast_groups.size() * sizeof(OrbxFastGroup), hipMemcpyHostToDevice));
     }
-    if (const char *e = getenv("ORBX_FAST_IMPL")) h->fast_impl = strcmp(e, "cells") == 0 ? 0 : 1;
     if (const char *e = getenv("ORBX_RESIZE_IMPL")) h->resize_legacy = strcmp(e, "legacy") == 0;
     if (const char *e = getenv("ORBX_FAST_STOP")) h->fast_stop = atoi(e);
     if (const char *e = getenv("ORBX_FAST_LCAP")) h->fast_lcap = std::max(64, atoi(e));
@@ -340,11 +338,8 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
         orbx_launch_pyr_resize(s, g, B, l, h->d_taps, h->d_pyr, h->geom.lv[l].narrow_taps && !h->resize_legacy);
     }
     { ProfScope ps(h, ORBX_K_FAST);
-      if (h->fast_impl == 1)
-          orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, (int)h->geom.fast_groups.size(), h->d_pyr, h->d_cand,
-                                h->d_cell_count, h->max_ch, h->fast_lcap, h->fast_stop);
-      else
-          orbx_launch_fast(s, g, B, h->d_cells, h->d_pyr, h->d_cand, h->d_cell_count, h->max_cw, h->max_ch, 0, g.ncells); }
+      orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, (int)h->geom.fast_groups.size(), h->d_pyr, h->d_cand,
+                            h->d_cell_count, h->max_ch, h->fast_lcap, h->fast_stop); }
     { ProfScope ps(h, ORBX_K_QUADTREE);
       orbx_launch_quadtree(s, g, B, h->d_cells, h->d_cand, h->d_cell_count, h->d_dense, h->d_cand_count, h->d_lvl_kp,
                            h->d_lvl_count, d_status, h->d_knode,

@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void k_pyr_l0_color(DGeom g, const uint8_t *__
 // in one pass: the border is produced by evaluating the bilinear formula at the reflected coordinate
 // (taps precomputed per padded coordinate on the host).  (reference :2119-2143)
 // ------------------------------------------------------------------------------------------------
-typedef uint2 __attribute__((aligned(1))) orbx_uint2_u;   // 8 bytes at any byte address (global memory takes unaligned accesses)
+struct __attribute__((packed, aligned(1))) orbx_uint2_u { uint32_t x, y; };   // 8 bytes at any byte address (global memory takes unaligned accesses)
+__device__ __forceinline__ uint2 orbx_load8(const void *p) { const orbx_uint2_u v = *(const orbx_uint2_u *)p; return make_uint2(v.x, v.y); }
 typedef unsigned short orbx_v2u16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t orbx_udot2(uint32_t a, uint32_t b) {   // a.lo * b.lo + a.hi * b.hi, exact
     return __builtin_amdgcn_udot2(__builtin_bit_cast(orbx_v2u16, a), __builtin_bit_cast(orbx_v2u16, b), 0u, false);
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const Or
 #pragma unroll
         for (int r = 0; r < RS_ROWS; ++r) {
             ty[r] = taps[L.tapy + min(Y0 + r, L.ph - 1)];
-            u[r] = *(const orbx_uint2_u *)(base + S.off + (long long)ty[r].s0 * S.pitch + smin);
-            w[r] = *(const orbx_uint2_u *)(base + S.off + (long long)ty[r].s1 * S.pitch + smin);
+            u[r] = orbx_load8(base + S.off + (long long)ty[r].s0 * S.pitch + smin);
+            w[r] = orbx_load8(base + S.off + (long long)ty[r].s1 * S.pitch + smin);
         }
 #pragma unroll
         for (int r = 0; r < RS_ROWS; ++r) {
@@ -208,80 +209,13 @@ __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const Or
     }
 }
 
-// Row-loop form of the narrow-footprint path (the one every usual geometry takes; the host checks the tap table and
+// Row-walking form of the narrow-footprint path (the one every usual geometry takes; the host checks the tap table and
 // launches k_pyr_resize above otherwise).  k_pyr_resize is latency-bound: tap records -> source loads -> store is a
-// chain of two dependent global loads per 512 bytes written, and its 256-pixel column strips leave up to 40 % of the
-// lanes of a level idle.  Here
-//   * the (row pair, dword column) items of RS2_RB row pairs are laid out linearly over the lanes, so every lane has
-//     work whatever the level width;
-//   * a lane keeps its horizontal selectors / weights in registers and walks `nit` blocks of rows; the vertical taps
-//     and source rows of step k+1 are requested before step k is evaluated: nothing in the loop waits on a table;
-//   * `nit` is chosen per level on the host so that small levels still fill the chip with waves.
-#define RS2_RB 4   // row pairs per block of rows
-__global__ __launch_bounds__(256) void k_pyr_resize_flat(DGeom g, int level, const OrbxTap *__restrict__ taps,
-                                                         uint8_t *__restrict__ pyr, int nit) {
-    const DLevel &L = g.lv[level];
-    const DLevel &S = g.lv[level - 1];
-    const int ndw = (L.pw + 3) >> 2;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= RS2_RB * ndw) return;
-    const int rp = q / ndw, X = 4 * (q - rp * ndw);
-    const int f = blockIdx.z;
-    const int y_first = blockIdx.y * (nit * 2 * RS2_RB) + 2 * rp;
-    if (y_first >= L.ph) return;
-    uint8_t *base = pyr + (long long)f * g.pyr_bytes;
-    const uint8_t *src = base + S.off;
-    uint8_t *dst = base + L.off + X;
-    uint32_t sel[4], wgt[4];
-    int smin = 0x7fff;
-    {
-        const uint2 *tq = (const uint2 *)taps + L.tapx;
-        uint2 t[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] = tq[min(X + i, L.pw - 1)];   // .x = s0 | s1 << 16, .y = a0 | a1 << 16
-#pragma unroll
-        for (int i = 0; i < 4; ++i) smin = min(smin, (int)(t[i].x & 0xffffu));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t d = (t[i].x & 0xffffu) - (uint32_t)smin;          // 0..6 (checked on the host)
-            sel[i] = d | (0x0cu << 8) | ((d + 1u) << 16) | (0x0cu << 24);
-            wgt[i] = t[i].y;
-        }
-    }
-    src += smin;
-    const uint2 *ty = (const uint2 *)taps + L.tapy;
-    const int ylast = L.ph - 1;
-    // prologue: taps and source rows of the first step
-    uint2 ta = ty[y_first], tb = ty[min(y_first + 1, ylast)];
-    uint2 ua = *(const orbx_uint2_u *)(src + (long long)(ta.x & 0xffffu) * S.pitch), wa = *(const orbx_uint2_u *)(src + (long long)(ta.x >> 16) * S.pitch);
-    uint2 ub = *(const orbx_uint2_u *)(src + (long long)(tb.x & 0xffffu) * S.pitch), wb = *(const orbx_uint2_u *)(src + (long long)(tb.x >> 16) * S.pitch);
-    int Y = y_first;
-    for (int it = 0; it < nit && Y < L.ph; ++it, Y += 2 * RS2_RB) {
-        const uint2 ca = ta, cb = tb, cua = ua, cwa = wa, cub = ub, cwb = wb;
-        {   // next step's rows, in flight while this step is evaluated (clamped past the end: loaded, never used)
-            const int Yn = min(Y + 2 * RS2_RB, ylast);
-            ta = ty[Yn]; tb = ty[min(Yn + 1, ylast)];
-            ua = *(const orbx_uint2_u *)(src + (long long)(ta.x & 0xffffu) * S.pitch); wa = *(const orbx_uint2_u *)(src + (long long)(ta.x >> 16) * S.pitch);
-            ub = *(const orbx_uint2_u *)(src + (long long)(tb.x & 0xffffu) * S.pitch); wb = *(const orbx_uint2_u *)(src + (long long)(tb.x >> 16) * S.pitch);
-        }
-        uint32_t va = 0, vb = 0;
-        const uint32_t a0 = ca.y & 0xfffu, a1 = (ca.y >> 16) & 0xfffu, b0 = cb.y & 0xfffu, b1 = (cb.y >> 16) & 0xfffu;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t T0 = orbx_udot2(__builtin_amdgcn_perm(cua.y, cua.x, sel[i]), wgt[i]);
-            const uint32_t T1 = orbx_udot2(__builtin_amdgcn_perm(cwa.y, cwa.x, sel[i]), wgt[i]);
-            const uint32_t T2 = orbx_udot2(__builtin_amdgcn_perm(cub.y, cub.x, sel[i]), wgt[i]);
-            const uint32_t T3 = orbx_udot2(__builtin_amdgcn_perm(cwb.y, cwb.x, sel[i]), wgt[i]);
-            va |= (((__umul24(a0, T0 >> 4) >> 16) + (__umul24(a1, T1 >> 4) >> 16) + 2u) >> 2) << (8 * i);
-            vb |= (((__umul24(b0, T2 >> 4) >> 16) + (__umul24(b1, T3 >> 4) >> 16) + 2u) >> 2) << (8 * i);
-        }
-        *(uint32_t *)(dst + (long long)Y * L.pitch) = va;
-        if (Y + 1 < L.ph) *(uint32_t *)(dst + (long long)(Y + 1) * L.pitch) = vb;
-    }
-}
-
-// Strip form: a wave owns a 256-pixel column strip (64 lanes x 4 px) and walks `rpw` destination rows, two per step;
-// the rows are wave-uniform, so the vertical taps are scalar loads.
+// chain of two dependent global loads per 512 bytes written.  Here a wave keeps its column strip's horizontal selectors /
+// weights in registers and walks `rpw` destination rows: the vertical taps are scalar loads (the row is wave-uniform),
+// the source rows of step k+1 are requested before step k is evaluated, and nothing in the loop waits on a table.
+// (A variant that lays (row pair, dword) items out linearly over the lanes to remove the idle lanes of odd level widths
+// measured 258 us against 207 us: vector tap loads, rows split across a wave.)
 __global__ __launch_bounds__(256) void k_pyr_resize_rows(DGeom g, int level, const OrbxTap *__restrict__ taps,
                                                          uint8_t *__restrict__ pyr, int rpw) {
     const DLevel &L = g.lv[level];
@@ -315,14 +249,14 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows(DGeom g, int level, con
     src += smin;
     const uint2 *ty = (const uint2 *)taps + L.tapy;
     uint2 ta = ty[y_begin], tb = ty[min(y_begin + 1, L.ph - 1)];
-    uint2 ua = *(const orbx_uint2_u *)(src + (long long)(ta.x & 0xffffu) * S.pitch), wa = *(const orbx_uint2_u *)(src + (long long)(ta.x >> 16) * S.pitch);
-    uint2 ub = *(const orbx_uint2_u *)(src + (long long)(tb.x & 0xffffu) * S.pitch), wb = *(const orbx_uint2_u *)(src + (long long)(tb.x >> 16) * S.pitch);
+    uint2 ua = orbx_load8(src + (long long)(ta.x & 0xffffu) * S.pitch), wa = orbx_load8(src + (long long)(ta.x >> 16) * S.pitch);
+    uint2 ub = orbx_load8(src + (long long)(tb.x & 0xffffu) * S.pitch), wb = orbx_load8(src + (long long)(tb.x >> 16) * S.pitch);
     for (int Y = y_begin; Y < y_end; Y += 2) {
         const uint2 ca = ta, cb = tb, cua = ua, cwa = wa, cub = ub, cwb = wb;
         if (Y + 2 < y_end) {   // next step's rows, in flight while this step is evaluated
             ta = ty[Y + 2]; tb = ty[min(Y + 3, L.ph - 1)];
-            ua = *(const orbx_uint2_u *)(src + (long long)(ta.x & 0xffffu) * S.pitch); wa = *(const orbx_uint2_u *)(src + (long long)(ta.x >> 16) * S.pitch);
-            ub = *(const orbx_uint2_u *)(src + (long long)(tb.x & 0xffffu) * S.pitch); wb = *(const orbx_uint2_u *)(src + (long long)(tb.x >> 16) * S.pitch);
+            ua = orbx_load8(src + (long long)(ta.x & 0xffffu) * S.pitch); wa = orbx_load8(src + (long long)(ta.x >> 16) * S.pitch);
+            ub = orbx_load8(src + (long long)(tb.x & 0xffffu) * S.pitch); wb = orbx_load8(src + (long long)(tb.x >> 16) * S.pitch);
         }
         uint32_t va = 0, vb = 0;
         const uint32_t a0 = ca.y & 0xfffu, a1 = (ca.y >> 16) & 0xfffu, b0 = cb.y & 0xfffu, b1 = (cb.y >> 16) & 0xfffu;
@@ -344,9 +278,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize_rows(DGeom g, int level, con
 
 // ------------------------------------------------------------------------------------------------
 // K2: FAST-9/16 + score + 3x3 strict NMS per cell, with the per-cell threshold retry
-// (reference src/ORBextractor.cc:1465-1548; cv::FAST semantics SURVEY App. B.1).
-// One wave (64 lanes) per cell; the cell tile, its score map and the corner list live in LDS.
-// Corners are compacted with wave ballot + mbcnt prefix; scores are only evaluated for compacted corners.
+// (reference src/ORBextractor.cc:1465-1548; cv::FAST semantics SURVEY App. B.1): helpers, then k_fast_rows.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool orbx_arc9(uint32_t mask16) {
     uint32_t m = mask16 | (mask16 << 16);
@@ -370,240 +302,10 @@ __device__ __forceinline__ void orbx_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#ifndef FAST_CPW
-#define FAST_CPW 2      // cells per wave (2 measured best of 1,2,4,8): prologue amortised, next tile prefetched into registers during compute
-#endif
-#ifndef FAST_WPS
-#define FAST_WPS 5      // __launch_bounds__ waves per SIMD (caps VGPRs at 96)
-#endif
-#define FAST_PF 10      // prefetch registers: 4 rows x 16 dwords per step -> cells up to 40 rows x 61 px (all but tiny levels)
-
-// FAST_TP (LDS tile pitch) is a template constant: row offsets become shifts/immediates instead of the quarter-rate
-// v_mul_lo_u32, and the 16 ring offsets fold into the ds_read offset field.  44 covers cells up to 38 px wide
-// (every level of the usual geometries), 72 the widest cells of tiny pyramid levels.
-template <int FAST_TP>
-__global__ __launch_bounds__(64, FAST_WPS) void k_fast_cells(DGeom g, const OrbxCell *__restrict__ cells,
-                                                   const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
-                                                   int *__restrict__ cell_count, int rows, int lcap,
-                                                   int cell_begin, int cell_end) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
-    const int lcap_b = (2 * lcap + 3) & ~3;
-    uint32_t *s_tile = (uint32_t *)fast_smem;
-    uint8_t *s_score = fast_smem + rows * FAST_TP;
-    uint16_t *s_list = (uint16_t *)(fast_smem + 2 * rows * FAST_TP);          // [0,nB): compass@min (bit 15: also @ini); back of the corner array: compass@ini
-    uint16_t *s_corn = (uint16_t *)(fast_smem + 2 * rows * FAST_TP + lcap_b);
-    // blockIdx.x = frame: workgroups are dealt round-robin over the 8 XCDs in linear-id order, so with the frame as
-    // the fastest grid dimension all cell groups of one frame share one XCD's L2 (overlapping tiles are fetched once)
-    const int lane = threadIdx.x;
-    const int f = blockIdx.x;
-    const int half = lane >> 5, lcol = lane & 31;
-    const int rq = lane >> 4, dq = lane & 15;
-    const bool two_th = g.min_th != g.ini_th;
-    // ring offsets in the LDS tile
-    const int ro[16] = {3 * FAST_TP,      3 * FAST_TP + 1,  2 * FAST_TP + 2,  FAST_TP + 3, 3,  -FAST_TP + 3,
-                        -2 * FAST_TP + 2, -3 * FAST_TP + 1, -3 * FAST_TP,     -3 * FAST_TP - 1, -2 * FAST_TP - 2,
-                        -FAST_TP - 3,     -3,               FAST_TP - 3,      2 * FAST_TP - 2,  3 * FAST_TP - 1};
-    const int cell0 = cell_begin + blockIdx.y * FAST_CPW;
-    const int ncell = min(FAST_CPW, cell_end - cell0);
-    uint32_t tv[FAST_PF];
-    // ---- prefetch of the first tile (all loads in flight before anything waits on them)
-    OrbxCell c = cells[cell0];
-    {
-        const DLevel &L = g.lv[c.level];
-        const int ndw = ((c.x0 & 3) + c.cw + 3) >> 2;
-        const uint8_t *src = pyr + (long long)f * g.pyr_bytes + L.off + (long long)c.y0 * L.pitch + (c.x0 & ~3) + 4 * min(dq, ndw - 1);
-#pragma unroll
-        for (int k = 0; k < FAST_PF; ++k) tv[k] = *(const uint32_t *)(src + (long long)min(4 * k + rq, c.ch - 1) * L.pitch);
-    }
-    for (int ci = 0; ci < ncell; ++ci) {
-        const DLevel &L = g.lv[c.level];
-        const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;
-        const int cw = c.cw, ch = c.ch;
-        const int xa = c.x0 & ~3, shift = c.x0 & 3;
-        const int ndw = (shift + cw + 3) >> 2;
-        // ---- tile: prefetched registers -> LDS; rows / columns beyond the register window come straight from memory
-#pragma unroll
-        for (int k = 0; k < FAST_PF; ++k) {
-            const int r = 4 * k + rq;
-            if (r < ch && dq < ndw) s_tile[r * (FAST_TP / 4) + dq] = tv[k];
-        }
-        if (ch > 4 * FAST_PF || ndw > 16)
-            for (int r = rq; r < ch; r += 4)
-                for (int d = dq; d < ndw; d += 16)
-                    if (r >= 4 * FAST_PF || d >= 16)
-                        s_tile[r * (FAST_TP / 4) + d] = *(const uint32_t *)(img + (long long)(c.y0 + r) * L.pitch + xa + 4 * d);
-        for (int i = lane; i < ch * (FAST_TP / 4); i += 64) ((uint32_t *)s_score)[i] = 0;
-        // ---- prefetch the next cell's tile; it lands while this cell is being processed
-        const OrbxCell cur = c;
-        if (ci + 1 < ncell) {
-            c = cells[cell0 + ci + 1];
-            const DLevel &Ln = g.lv[c.level];
-            const int ndwn = ((c.x0 & 3) + c.cw + 3) >> 2;
-            const uint8_t *src = pyr + (long long)f * g.pyr_bytes + Ln.off + (long long)c.y0 * Ln.pitch + (c.x0 & ~3) + 4 * min(dq, ndwn - 1);
-#pragma unroll
-            for (int k = 0; k < FAST_PF; ++k) tv[k] = *(const uint32_t *)(src + (long long)min(4 * k + rq, c.ch - 1) * Ln.pitch);
-        }
-        const uint8_t *tile = (const uint8_t *)s_tile + shift;
-        orbx_wave_sync();
-        // ---- phase 1a: compass pre-test of EVERY interior pixel for both thresholds in one sweep.  A 9-arc of the
-        // 16-ring contains one pixel of every opposite pair, so e = max(min(max(r0,r8),max(r4,r12)) - v,
-        // v - max(min(r0,r8),min(r4,r12))) > th is necessary for a corner.  Two rows per lane per step.
-        int nA = 0, nB = 0;
-        for (int yb = 3; yb < ch - 3; yb += 4) {
-            for (int x0 = 3; x0 < cw - 3; x0 += 32) {
-                const int lx = x0 + lcol;
-                const int ly0 = yb + 2 * half, ly1 = ly0 + 1;
-                const bool act0 = lx < cw - 3 && ly0 < ch - 3, act1 = lx < cw - 3 && ly1 < ch - 3;
-                const uint8_t *p0 = tile + (act0 ? ly0 : 3) * FAST_TP + (act0 ? lx : 3);
-                const uint8_t *p1 = tile + (act1 ? ly1 : 3) * FAST_TP + (act1 ? lx : 3);
-                const int v0 = p0[0], a0 = p0[ro[0]], a4 = p0[ro[4]], a8 = p0[ro[8]], a12 = p0[ro[12]];
-                const int v1 = p1[0], b0 = p1[ro[0]], b4 = p1[ro[4]], b8 = p1[ro[8]], b12 = p1[ro[12]];
-                int e0 = max(min(max(a0, a8), max(a4, a12)) - v0, v0 - max(min(a0, a8), min(a4, a12)));
-                int e1 = max(min(max(b0, b8), max(b4, b12)) - v1, v1 - max(min(b0, b8), min(b4, b12)));
-                e0 = act0 ? e0 : -1;
-                e1 = act1 ? e1 : -1;
-                // ONE compaction per pixel slot: everything that passes at minThFAST goes to the front of the list,
-                // bit 15 of the code remembers whether it also passes at iniThFAST
-                const uint16_t code0 = (uint16_t)((ly0 << 8) | lx | ((e0 > g.ini_th) ? 0x8000 : 0));
-                const uint16_t code1 = (uint16_t)((ly1 << 8) | lx | ((e1 > g.ini_th) ? 0x8000 : 0));
-                const unsigned long long m0 = __ballot(e0 > g.min_th), m1 = __ballot(e1 > g.min_th);
-                if (e0 > g.min_th) s_list[nB + orbx_wave_rank(m0)] = code0;
-                nB += __popcll(m0);
-                if (e1 > g.min_th) s_list[nB + orbx_wave_rank(m1)] = code1;
-                nB += __popcll(m1);
-            }
-        }
-        orbx_wave_sync();
-        // the (usually much shorter) iniThFAST list is filtered out of the front list into the BACK of the corner array
-        // (its front receives the corners of the pass).  If more than half of the cell passed at iniThFAST the two
-        // could collide: then pass 0 simply walks the front list and masks the lanes whose flag is clear.
-        bool a_in_back = false;
-        if (two_th) {
-            int na = 0;
-            for (int e0 = 0; e0 < nB; e0 += 64) {
-                const int e = e0 + lane;
-                na += __popcll(__ballot(e < nB && (s_list[e] & 0x8000) != 0));
-            }
-            a_in_back = 2 * na <= lcap;
-            if (a_in_back) {
-                for (int e0 = 0; e0 < nB; e0 += 64) {
-                    const int e = e0 + lane;
-                    const uint16_t code = e < nB ? s_list[e] : (uint16_t)0;
-                    const bool isA = (code & 0x8000) != 0;
-                    const unsigned long long m = __ballot(isA);
-                    if (isA) s_corn[lcap - 1 - (nA + orbx_wave_rank(m))] = (uint16_t)(code & 0x7fff);
-                    nA += __popcll(m);
-                }
-            } else {
-                nA = nB;   // walk the whole front list, flag-masked
-            }
-        } else {
-            nA = nB;       // one threshold: the front list IS the list of the only pass
-        }
-        orbx_wave_sync();
-        uint2 *out = cand + (long long)f * g.cand_total + L.cand_begin + cur.slot_begin;
-        int nsurv = 0;
-        for (int pass = 0; pass < 2; ++pass) {
-            const int th = pass == 0 ? g.ini_th : g.min_th;
-            const int nlist = pass == 0 ? nA : nB;
-            // ---- phase 1b: full 16-ring test of the pre-selected pixels
-            int ncorn = 0;
-            for (int e0 = 0; e0 < nlist; e0 += 64) {
-                const int e = e0 + lane;
-                const bool valid = e < nlist;
-                uint16_t code = (uint16_t)((3 << 8) | 3);
-                bool use = valid;
-                if (valid) {
-                    const uint16_t raw = (pass == 0 && a_in_back) ? s_corn[lcap - 1 - e] : s_list[e];
-                    if (pass == 0 && two_th && !a_in_back) use = (raw & 0x8000) != 0;   // flag-masked walk
-                    code = use ? (uint16_t)(raw & 0x7fff) : code;
-                }
-                const uint8_t *ptr = tile + (code >> 8) * FAST_TP + (code & 0xff);
-                const int v = ptr[0];
-                const int hi = v + th, lo = v - th;
-                uint32_t bright = 0, dark = 0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int x = ptr[ro[k]];
-                    bright |= x > hi ? (1u << k) : 0u;   // v_cndmask(literal) + v_or: both full rate on gfx950
-                    dark |= x < lo ? (1u << k) : 0u;     // (v_lshl_or_b32 is a half-rate VOP3)
-                }
-                const bool corner = (int)use & ((int)orbx_arc9(bright) | (int)orbx_arc9(dark));
-                const unsigned long long m = __ballot(corner);
-                if (corner) s_corn[ncorn + orbx_wave_rank(m)] = code;
-                ncorn += __popcll(m);
-            }
-            orbx_wave_sync();
-            // ---- phase 2: score of every corner: max(th, max_arc min d, max_arc min -d) - 1
-            for (int e = lane; e < ncorn; e += 64) {
-                const int lx = s_corn[e] & 0xff, ly = s_corn[e] >> 8;
-                const uint8_t *ptr = tile + ly * FAST_TP + lx;
-                const int v = ptr[0];
-                int d[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) d[k] = v - (int)ptr[ro[k]];
-                // sliding 9-window extrema over the circular ring by doubling (2, 4, 8, +1); the two polarities are
-                // evaluated one after the other to keep the live register set small
-                int a0 = th, b0 = -th;  // a0: best "ring darker" arc, b0: -(best "ring brighter" arc)
-                {
-                    int m2[16], m4[16];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) m2[k] = min(d[k], d[(k + 1) & 15]);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) m4[k] = min(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) a0 = max(a0, min(min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
-                }
-                {
-                    int m2[16], m4[16];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) m2[k] = max(d[k], d[(k + 1) & 15]);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) m4[k] = max(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) b0 = min(b0, max(max(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
-                }
-                s_score[ly * FAST_TP + lx] = (uint8_t)(max(a0, -b0) - 1);
-            }
-            orbx_wave_sync();
-            // ---- phase 3: 3x3 strict NMS among the corners of THIS cell only; survivors go straight to the cell's
-            // private slot range (no atomics, no staging)
-            nsurv = 0;
-            for (int e0 = 0; e0 < ncorn; e0 += 64) {
-                const int e = e0 + lane;
-                const bool valid = e < ncorn;
-                const uint16_t code = valid ? s_corn[e] : (uint16_t)((3 << 8) | 3);
-                const int lx = code & 0xff, ly = code >> 8;
-                const uint8_t *sp = s_score + ly * FAST_TP + lx;
-                const int sc = sp[0];
-                const int n0 = sp[1], n1 = sp[-1], n2 = sp[-FAST_TP - 1], n3 = sp[-FAST_TP], n4 = sp[-FAST_TP + 1],
-                          n5 = sp[FAST_TP - 1], n6 = sp[FAST_TP], n7 = sp[FAST_TP + 1];
-                const bool keep = (int)valid & (int)(sc > n0) & (int)(sc > n1) & (int)(sc > n2) & (int)(sc > n3) &
-                                  (int)(sc > n4) & (int)(sc > n5) & (int)(sc > n6) & (int)(sc > n7);
-                const unsigned long long m = __ballot(keep);
-                const int slot = nsurv + orbx_wave_rank(m);
-                if (keep && slot < cur.slot_cap) {
-                    uint2 o;
-                    o.x = (uint32_t)(lx + cur.offx) | ((uint32_t)(ly + cur.offy) << 12) | ((uint32_t)sc << 24);
-                    o.y = ((uint32_t)cur.idx_in_level << 12) | ((uint32_t)ly << 6) | (uint32_t)lx;  // emission order key
-                    out[slot] = o;
-                }
-                nsurv += __popcll(m);
-            }
-            if (nsurv > 0 || !two_th) break;  // vKeysCell.empty() -> retry with minThFAST (:1519-1527)
-            // the retry recomputes every score with the lower threshold: clear the scores of the first attempt
-            orbx_wave_sync();
-            for (int e = lane; e < ncorn; e += 64) s_score[(s_corn[e] >> 8) * FAST_TP + (s_corn[e] & 0xff)] = 0;
-            orbx_wave_sync();
-        }
-        if (lane == 0) cell_count[(long long)f * g.ncells + cell0 + ci] = nsurv;
-        orbx_wave_sync();   // the next cell overwrites tile / score / lists
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// K2 (row-walk formulation): the same per-cell FAST-9/16 + score + NMS + threshold retry, organised so that the
-// dense part costs a dozen vector instructions per image ROW instead of per pixel pair:
+// k_fast_rows: per-cell FAST-9/16 + score + NMS + threshold retry, organised so that the dense part costs a dozen vector
+// instructions per image ROW (the first version, one wave per cell with a compass test per pixel pair, took 532 us per
+// 256 frames against 390 us; git history has it):
 //   * one wave owns a GROUP of one or two horizontally adjacent cells (OrbxFastGroup); lane i is interior column i of
 //     the group and walks down the rows with the column's 7-row window in registers (one LDS byte per row), the two
 //     horizontal compass pixels come from LDS with immediate offsets -- no per-pixel address arithmetic;
@@ -613,7 +315,6 @@ __global__ __launch_bounds__(64, FAST_WPS) void k_fast_cells(DGeom g, const Orbx
 //     LDS list; the list is flushed through the full ring test + score whenever the next row might not fit, so the
 //     LDS footprint is independent of how many pixels pass;
 //   * NMS walks the corner list when every corner of the group fitted it, otherwise it rescans the score map.
-// Results (candidate records, per-cell counts) are identical to k_fast_cells.
 // ------------------------------------------------------------------------------------------------
 #ifndef FR_TP
 #define FR_TP 76        // LDS tile pitch: 64 interior columns + 6 ring + 3 alignment bytes -> 19 dwords (odd: rows spread over all banks)
@@ -643,79 +344,6 @@ struct FrCtx {
 
 // full 16-ring test of list[0..n) at threshold th, corners compacted IN PLACE to the front of the list, their scores
 // written to the score map; returns the number of corners
-// FR_SCORE_FIRST = 1 replaces "ring masks, then the score of the corners" by the score network on every candidate
-// (corner <=> network result > th).  Measured on MI355X: 460 us against 408 us per 256 frames -- pixels on diagonal
-// edges pass BOTH halves of the compass test, nearly every round of 64 candidates holds one, and the second network
-// evaluation that costs is not the rare branch it looks like.  Kept as a build knob; results are identical.
-#ifndef FR_SCORE_FIRST
-#define FR_SCORE_FIRST 0
-#endif
-#if FR_SCORE_FIRST
-// Corner test and score of list[0..n) in ONE pass: the score network of a single polarity (64 16-bit min/max) is
-// cheaper than building both 16-bit ring masks (64 v_cmp/v_addc + two run tests), and it answers both questions:
-//   m = max over the 16 arcs of the min over the arc of +-(ring - v);  corner  <=>  m > th;  score = m - 1
-// (cv::FAST's test and cv::cornerScore<16>).  The polarity comes from the compass values (which of the two halves of
-// the pre-test passed); both can pass (then both are evaluated, a wave-uniform and rare branch), only one can be a
-// corner.  Corners are compacted IN PLACE to the front of the list, their scores written to the score map.
-__device__ __forceinline__ fr_i16 fr_arc_maxmin(const fr_i16 *d) {
-    fr_i16 m2[16], m4[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) m2[k] = fr_smin(d[k], d[(k + 1) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) m4[k] = fr_smin(m2[k], m2[(k + 2) & 15]);
-    fr_i16 a0 = (fr_i16)-512;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a0 = fr_smax(a0, fr_smin(fr_smin(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
-    return a0;
-}
-__device__ __forceinline__ int fr_ring_and_score(const FrCtx &c, int n, int th, int dbg_stop) {
-    const int ro[16] = {3 * FR_TP,      3 * FR_TP + 1,  2 * FR_TP + 2,  FR_TP + 3, 3,  -FR_TP + 3,
-                        -2 * FR_TP + 2, -3 * FR_TP + 1, -3 * FR_TP,     -3 * FR_TP - 1, -2 * FR_TP - 2,
-                        -FR_TP - 3,     -3,             FR_TP - 3,      2 * FR_TP - 2,  3 * FR_TP - 1};
-    int ncorn = 0;
-    const fr_i16 th16 = (fr_i16)th;
-    for (int e0 = 0; e0 < n; e0 += 64) {
-        const int e = e0 + c.lane;
-        const bool valid = e < n;
-        const uint16_t code = valid ? c.list[e] : (uint16_t)(3 << 8);
-        const int off = (code >> 8) * FR_TP + 3 + (code & 0xff);
-        const uint8_t *ptr = c.tile + off;
-        fr_u16 x[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = ptr[ro[k]];
-        const fr_u16 vu = ptr[0];
-        // which half of the compass pre-test passed (ring positions 0, 4, 8, 12)
-        const fr_u16 A = fr_min(fr_max(x[0], x[8]), fr_max(x[4], x[12]));
-        const fr_u16 Bm = fr_max(fr_min(x[0], x[8]), fr_min(x[4], x[12]));
-        const bool tb = (fr_i16)(A - vu) > th16, td = (fr_i16)(vu - Bm) > th16;
-        // darker ring: complement both sides, (255 - x) - (255 - v) = v - x: one instruction stream serves both cases
-        const fr_u16 flip = tb ? (fr_u16)0 : (fr_u16)0xff;
-        const fr_i16 v = (fr_i16)(vu ^ flip);
-        fr_i16 d[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = (fr_i16)((fr_i16)(x[k] ^ flip) - v);
-        fr_i16 m = fr_arc_maxmin(d);
-        bool brighter = tb;
-        if (orbx_ballot(tb & td) != 0ull) {   // both halves passed somewhere in the wave: those lanes also try the dark ring
-#pragma unroll
-            for (int k = 0; k < 16; ++k) d[k] = (fr_i16)((fr_i16)(x[k] ^ (fr_u16)0xff) - (fr_i16)(vu ^ (fr_u16)0xff));
-            const fr_i16 m2 = fr_arc_maxmin(d);
-            if ((tb & td) && m2 > m) { m = m2; brighter = false; }
-        }
-        (void)brighter;
-        const bool corner = (int)valid & (int)(m > th16);
-        const unsigned long long mk = orbx_ballot(corner);
-        // index <= e: this round's entries are already in registers
-        if (corner) {
-            c.list[ncorn + orbx_wave_rank(mk)] = code;
-            if (dbg_stop != 3) c.score[off] = (uint8_t)(m - 1);
-        }
-        ncorn += __popcll(mk);
-    }
-    orbx_wave_sync();
-    return ncorn;
-}
-#else
 __device__ __forceinline__ int fr_ring_and_score(const FrCtx &c, int n, int th, int dbg_stop) {
     const int ro[16] = {3 * FR_TP,      3 * FR_TP + 1,  2 * FR_TP + 2,  FR_TP + 3, 3,  -FR_TP + 3,
                         -2 * FR_TP + 2, -3 * FR_TP + 1, -3 * FR_TP,     -3 * FR_TP - 1, -2 * FR_TP - 2,
@@ -779,7 +407,6 @@ __device__ __forceinline__ int fr_ring_and_score(const FrCtx &c, int n, int th, 
     orbx_wave_sync();
     return ncorn;
 }
-#endif
 
 
 // strict 3x3 NMS of list[0..n) among the corners of the SAME cell, survivors straight to the cell's slot range
@@ -910,7 +537,6 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     for (int pass = 0; pass < 2; ++pass) {
         const int th = pass == 0 ? g.ini_th : g.min_th;
         const bool lane_on = colv && ((act >> (second ? 1 : 0)) & 1u);
-        const unsigned long long lanes_on = orbx_ballot(lane_on);
         int nctot = 0;
         bool overflow = false;
         int y = 3;
@@ -2138,47 +1764,16 @@ void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr, bool narrow) {
     const DLevel &L = g.lv[level];
     if (narrow) {
-        static int impl = -1, par = 0;
-        if (impl < 0) {   // ORBX_RESIZE_IMPL=flat[:nit] / rows[:rpw] (A/B runs); default rows:16
-            const char *e = getenv("ORBX_RESIZE_IMPL");
-            impl = (e && strncmp(e, "flat", 4) == 0) ? 1 : 0;
-            const char *c = e ? strchr(e, ':') : nullptr;
-            par = c ? atoi(c + 1) : 0;
-        }
-        if (impl == 1) {
-            const int ndw = (L.pw + 3) / 4, bx = (RS2_RB * ndw + 255) / 256;
-            const int row_blocks = (L.ph + 2 * RS2_RB - 1) / (2 * RS2_RB);
-            const int nit = par > 0 ? par : 8;
-            dim3 grid(bx, (row_blocks + nit - 1) / nit, B);
-            hipLaunchKernelGGL(k_pyr_resize_flat, grid, dim3(256), 0, s, g, level, taps, pyr, nit);
-        } else {
-            // destination rows per wave: 16 when the launch still has >= 4096 waves, fewer for small batches (the rows of a
-            // wave are a serial chain of load -> evaluate -> store steps)
-            int rpw = par > 0 ? par : 16;
-            if (par <= 0)
-                while (rpw > 2 && (long long)((L.pw + 255) / 256) * ((L.ph + rpw - 1) / rpw) * B < 4096) rpw >>= 1;
-            dim3 grid((L.pw + 255) / 256, (L.ph + 4 * rpw - 1) / (4 * rpw), B);
-            hipLaunchKernelGGL(k_pyr_resize_rows, grid, dim3(64, 4), 0, s, g, level, taps, pyr, rpw);
-        }
+        // destination rows per wave: 16 when the launch still has >= 4096 waves, fewer for small batches (the rows of a
+        // wave are a serial chain of load -> evaluate -> store steps)
+        int rpw = 16;
+        while (rpw > 2 && (long long)((L.pw + 255) / 256) * ((L.ph + rpw - 1) / rpw) * B < 4096) rpw >>= 1;
+        dim3 grid((L.pw + 255) / 256, (L.ph + 4 * rpw - 1) / (4 * rpw), B);
+        hipLaunchKernelGGL(k_pyr_resize_rows, grid, dim3(64, 4), 0, s, g, level, taps, pyr, rpw);
         return;
     }
     dim3 grid((L.pw + 255) / 256, (L.ph + 4 * RS_ROWS - 1) / (4 * RS_ROWS), B);
     hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, g, level, taps, pyr);
-}
-void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint8_t *pyr, uint2 *cand,
-                      int *cell_count, int max_cw, int max_ch, int cell_begin, int cell_end) {
-    if (cell_end <= cell_begin) return;
-    const int need = (max_cw + 3 + 3) & ~3;         // +3: dword-alignment shift of the tile origin
-    const int tp = need <= 44 ? 44 : 72;            // template instances of the tile pitch (host geometry caps cw at 67)
-    const int lcap = (max_cw - 6) * (max_ch - 6);   // every interior pixel could pass the pre-test
-    const size_t smem = (size_t)2 * max_ch * tp + 2 * (size_t)((2 * lcap + 3) & ~3);
-    const dim3 grid(B, (cell_end - cell_begin + FAST_CPW - 1) / FAST_CPW);
-    if (tp == 44)
-        hipLaunchKernelGGL(k_fast_cells<44>, grid, dim3(64), smem, s, g, cells, pyr, cand, cell_count, max_ch, lcap, cell_begin,
-                           cell_end);
-    else
-        hipLaunchKernelGGL(k_fast_cells<72>, grid, dim3(64), smem, s, g, cells, pyr, cand, cell_count, max_ch, lcap, cell_begin,
-                           cell_end);
 }
 void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *groups,
                            int ngroups, const uint8_t *pyr, uint2 *cand, int *cell_count, int max_ch, int lcap, int dbg_stop) {

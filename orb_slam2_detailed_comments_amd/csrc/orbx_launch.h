@@ -12,8 +12,6 @@ void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *img
 void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
                               long long frame_stride, uint8_t *pyr, int nch, int r_off, int b_off);
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr, bool narrow);
-void orbx_launch_fast(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint8_t *pyr, uint2 *cand,
-                      int *cell_count, int max_cw, int max_ch, int cell_begin, int cell_end);
 void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *groups,
                            int ngroups, const uint8_t *pyr, uint2 *cand, int *cell_count, int max_ch, int lcap, int dbg_stop);
 void orbx_launch_bow_transform(hipStream_t s, int B, int max_n, const int *child_begin, const uint32_t *child_ids,

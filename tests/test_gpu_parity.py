@@ -363,14 +363,3 @@ def test_fast_rows_small_work_list_flush_and_rescan_paths(lcap, monkeypatch):
     img = rng.integers(0, 256, size=(240, 320), dtype=np.uint8)   # dense corners everywhere
     k, d = ORBextractor(500)(img)
     assert_frame_equal((k, d), oracle.OracleExtractor(500).extract(img), "noise")
-
-
-def test_fast_legacy_cell_kernel_still_matches(monkeypatch):
-    monkeypatch.setenv("ORBX_FAST_IMPL", "cells")
-    frames = synth.stream(640, 480, 1, stream_id=23)
-    ex = ORBextractor(1000, 1.2, 8, 20, 7)
-    res = ex.extract_batch(frames)
-    orc = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
-    out = orc.extract(frames[0], cap=ex.max_keypoints(640, 480))
-    check_stages(ex, orc, 0)
-    assert_frame_equal(res[0], out, "legacy FAST kernel")
