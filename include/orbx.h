@@ -14,6 +14,7 @@
  */
 #ifndef ORBX_H
 #define ORBX_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -329,6 +330,14 @@ orbx_status orbx_bow_transform_device(orbx_handle *h, const orbx_vocabulary *voc
 orbx_status orbx_bow_vectors(const orbx_vocabulary *voc, const uint32_t *word_id, const double *weight,
                              const uint32_t *node_id, int n, uint32_t *bow_word, double *bow_value, int *n_bow,
                              uint32_t *fv_node, int32_t *fv_begin, uint32_t *fv_index, int *n_fv_nodes);
+
+/* Page-locked host memory for the host-buffer entry points: with it every upload / download of orbx_extract_batch is an
+ * asynchronous DMA that overlaps the kernels of the neighbouring chunks (pageable memory works too, the runtime then
+ * stages the copies and blocks the calling thread while it does).  A call with more frames than the handle's max_batch is
+ * processed in chunks of max_batch frames, the upload of chunk c+1 and the download of chunk c-1 overlapping the kernels of
+ * chunk c.  NULL on failure. */
+void *orbx_host_alloc(size_t bytes);
+void orbx_host_free(void *p);
 
 /* ---- stream / timing plumbing ------------------------------------------------------------ */
 void *orbx_get_stream(orbx_handle *h);            /* hipStream_t */

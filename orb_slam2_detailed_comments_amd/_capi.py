@@ -92,7 +92,7 @@ SYMBOLS = [
     "orbx_search_by_projection_mappoints", "orbx_set_input_format", "orbx_search_by_bow_keyframe_frame",
     "orbx_search_by_bow_keyframes", "orbx_search_for_triangulation", "orbx_fuse", "orbx_fuse_sim3",
     "orbx_search_by_projection_sim3", "orbx_search_by_sim3", "orbx_search_by_projection_keyframe",
-    "orbx_stereo_match_batch_device", "orbx_vocabulary_create", "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_bow_transform_device", "orbx_bow_vectors",
+    "orbx_stereo_match_batch_device", "orbx_host_alloc", "orbx_host_free", "orbx_vocabulary_create", "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_bow_transform_device", "orbx_bow_vectors",
 ]
 
 _lib = None
@@ -184,6 +184,8 @@ def lib():
     L.orbx_bow_vectors.argtypes = [vp, vp, vp, vp, i32, vp, vp, C.POINTER(i32), vp, vp, vp, C.POINTER(i32)]
     L.orbx_stereo_match_batch_device.restype = i32
     L.orbx_stereo_match_batch_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp]
+    L.orbx_host_alloc.restype = vp; L.orbx_host_alloc.argtypes = [C.c_size_t]
+    L.orbx_host_free.restype = None; L.orbx_host_free.argtypes = [vp]
     _lib = L
     return L
 
@@ -203,3 +205,22 @@ def ptr(a):
     if isinstance(a, int):
         return C.c_void_p(a)
     return C.c_void_p(a.data_ptr())
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory (orbx_host_alloc); keep the object alive as long as the array is used"""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = lib().orbx_host_alloc(self.nbytes)
+        if not self._p:
+            raise MemoryError("orbx_host_alloc failed")
+        self.array = np.frombuffer((C.c_uint8 * self.nbytes).from_address(self._p), dtype=dtype).reshape(shape)
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            try:
+                lib().orbx_host_free(self._p)
+            except Exception:
+                pass
+            self._p = None

@@ -52,9 +52,11 @@ struct orbx_handle {
     uint16_t *d_knode = nullptr;
     int max_cw = 0, max_ch = 0, ncap = 0, lds_keys = 0;
     // staging for the host entry points
-    uint8_t *d_in = nullptr; size_t d_in_bytes = 0;
-    orbx_keypoint *d_kps = nullptr; uint8_t *d_desc = nullptr; int *d_counts = nullptr; int *d_ustatus = nullptr;
-    int out_cap = 0;
+    uint8_t *st_in[2] = {nullptr, nullptr}; size_t d_in_bytes = 0;
+    orbx_keypoint *st_kps[2] = {nullptr, nullptr}; uint8_t *st_desc[2] = {nullptr, nullptr}; int *st_cnt[2] = {nullptr, nullptr};
+    int out_cap = 0, stage_chunk = 0;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     int last_batch = 0;
     int mk_w = 0, mk_h = 0, mk_total = 0;   // orbx_max_keypoints cache
     void *d_match_ws = nullptr; size_t match_ws_bytes = 0;   // partial (best, second) keys of k_match
@@ -266,7 +268,13 @@ extern "C" void orbx_destroy(orbx_handle *h) {
         for (auto e : h->pool) hipEventDestroy(e);
         free_geometry_buffers(h);
         hipFree(h->d_match_ws); hipFree(h->d_scratch);
-        hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_ustatus);
+        for (int s = 0; s < 2; ++s) {
+            hipFree(h->st_in[s]); hipFree(h->st_kps[s]); hipFree(h->st_desc[s]); hipFree(h->st_cnt[s]);
+            if (h->ev_in[s]) hipEventDestroy(h->ev_in[s]);
+            if (h->ev_done[s]) hipEventDestroy(h->ev_done[s]);
+        }
+        if (h->s_in) hipStreamDestroy(h->s_in);
+        if (h->s_out) hipStreamDestroy(h->s_out);
         if (h->own_stream) hipStreamDestroy(h->own_stream);
     }
     delete h;
@@ -375,25 +383,45 @@ extern "C" orbx_status orbx_extract_batch_device(orbx_handle *h, int nframes, co
     return ORBX_OK;
 }
 
-static orbx_status ensure_staging(orbx_handle *h, size_t in_bytes, int cap) {
-    const int MB = h->p.max_batch;
-    if (in_bytes > h->d_in_bytes) {
-        hipFree(h->d_in); h->d_in = nullptr; h->d_in_bytes = 0;
-        HIPCHK(hipMalloc(&h->d_in, in_bytes));
-        h->d_in_bytes = in_bytes;
+// Host-buffer entry point: two sets of device staging buffers and two copy streams, so that the upload of chunk c+1 and
+// the download of chunk c-1 overlap the kernels of chunk c.  With pageable host memory hipMemcpyAsync stages through the
+// runtime's pinned buffers and blocks the calling thread while it does (the GPU keeps computing meanwhile); with pinned
+// memory (orbx_host_alloc, or any hipHostMalloc / hipHostRegister memory) every copy is a plain asynchronous DMA.
+static orbx_status ensure_staging(orbx_handle *h, size_t in_bytes, int cap, int chunk) {
+    if (in_bytes > h->d_in_bytes || cap > h->out_cap || chunk > h->stage_chunk) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const size_t inb = std::max(in_bytes, h->d_in_bytes);
+        const int c = std::max(cap, h->out_cap), ch = std::max(chunk, h->stage_chunk);
+        for (int s = 0; s < 2; ++s) {
+            hipFree(h->st_in[s]); hipFree(h->st_kps[s]); hipFree(h->st_desc[s]); hipFree(h->st_cnt[s]);
+            h->st_in[s] = nullptr; h->st_kps[s] = nullptr; h->st_desc[s] = nullptr; h->st_cnt[s] = nullptr;
+        }
+        h->d_in_bytes = 0; h->out_cap = 0; h->stage_chunk = 0;
+        for (int s = 0; s < 2; ++s) {
+            HIPCHK(hipMalloc(&h->st_in[s], inb));
+            HIPCHK(hipMalloc(&h->st_kps[s], (size_t)ch * c * sizeof(orbx_keypoint)));
+            HIPCHK(hipMalloc(&h->st_desc[s], (size_t)ch * c * 32));
+            HIPCHK(hipMalloc(&h->st_cnt[s], (size_t)2 * ch * sizeof(int)));   // counts | status
+        }
+        h->d_in_bytes = inb; h->out_cap = c; h->stage_chunk = ch;
     }
-    if (cap > h->out_cap) {
-        hipFree(h->d_kps); hipFree(h->d_desc); h->d_kps = nullptr; h->d_desc = nullptr; h->out_cap = 0;
-        HIPCHK(hipMalloc(&h->d_kps, (size_t)MB * cap * sizeof(orbx_keypoint)));
-        HIPCHK(hipMalloc(&h->d_desc, (size_t)MB * cap * 32));
-        h->out_cap = cap;
-    }
-    if (!h->d_counts) {
-        HIPCHK(hipMalloc(&h->d_counts, (size_t)MB * sizeof(int)));
-        HIPCHK(hipMalloc(&h->d_ustatus, (size_t)MB * sizeof(int)));
+    if (!h->s_in) {
+        HIPCHK(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+        for (int s = 0; s < 2; ++s) {
+            HIPCHK(hipEventCreateWithFlags(&h->ev_in[s], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
+        }
     }
     return ORBX_OK;
 }
+
+extern "C" void *orbx_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void orbx_host_free(void *p) { if (p) hipHostFree(p); }
 
 extern "C" orbx_status orbx_extract_batch(orbx_handle *h, int nframes, const uint8_t *imgs, int width, int height,
                                           int stride, int64_t frame_stride, orbx_keypoint *kps, uint8_t *desc,
@@ -405,29 +433,61 @@ extern "C" orbx_status orbx_extract_batch(orbx_handle *h, int nframes, const uin
     if (st != ORBX_OK) return st;
     HIPCHK(hipSetDevice(h->dev));
     const int MB = h->p.max_batch;
+    // chunks of max_batch frames (all frames of a call that fits one chunk stay resident for the pyramid accessors);
+    // longer calls are pipelined chunk by chunk
+    const int chunk = std::min(MB, nframes);
     const size_t fbytes = (size_t)stride * height;
-    st = ensure_staging(h, (size_t)MB * fbytes, cap);
+    st = ensure_staging(h, (size_t)chunk * fbytes, cap, chunk);
     if (st != ORBX_OK) return st;
+    const int nchunks = (nframes + chunk - 1) / chunk;
+    std::vector<int> hstat((size_t)2 * chunk);
     orbx_status worst = ORBX_OK;
-    std::vector<int> hstat(MB);
-    for (int f0 = 0; f0 < nframes; f0 += MB) {
-        const int B = std::min(MB, nframes - f0);
-        for (int i = 0; i < B; ++i)
-            HIPCHK(hipMemcpyAsync(h->d_in + (size_t)i * fbytes, imgs + (int64_t)(f0 + i) * frame_stride, fbytes,
-                                  hipMemcpyHostToDevice, h->stream));
-        st = run_chunk(h, B, h->d_in, width, height, stride, (int64_t)fbytes, h->d_kps, h->d_desc, h->d_counts,
-                       h->d_ustatus, cap);
-        if (st != ORBX_OK) return st;
-        HIPCHK(hipMemcpyAsync(kps + (int64_t)f0 * cap, h->d_kps, (size_t)B * cap * sizeof(orbx_keypoint),
-                              hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(desc + (int64_t)f0 * cap * 32, h->d_desc, (size_t)B * cap * 32, hipMemcpyDeviceToHost,
-                              h->stream));
-        HIPCHK(hipMemcpyAsync(counts + f0, h->d_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(hstat.data(), h->d_ustatus, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        for (int i = 0; i < B; ++i)
-            if (hstat[i] != ORBX_OK) worst = (orbx_status)hstat[i];
+    // a single chunk needs no second stream: copies and kernels in order on the handle's stream (the latency path)
+    const bool piped = nchunks > 1;
+    hipStream_t sin = piped ? h->s_in : h->stream, sout = piped ? h->s_out : h->stream;
+    auto upload = [&](int c) -> hipError_t {
+        const int s = c & 1, f0 = c * chunk, B = std::min(chunk, nframes - f0);
+        if (c >= 2) {   // the kernels of chunk c-2 read this input set
+            const hipError_t e = hipStreamWaitEvent(sin, h->ev_done[s], 0);
+            if (e != hipSuccess) return e;
+        }
+        if (frame_stride == (int64_t)fbytes) {   // frames back to back: one copy per chunk
+            const hipError_t e = hipMemcpyAsync(h->st_in[s], imgs + (int64_t)f0 * frame_stride, (size_t)B * fbytes, hipMemcpyHostToDevice, sin);
+            if (e != hipSuccess) return e;
+        } else {
+            for (int i = 0; i < B; ++i) {
+                const hipError_t e = hipMemcpyAsync(h->st_in[s] + (size_t)i * fbytes, imgs + (int64_t)(f0 + i) * frame_stride, fbytes,
+                                                    hipMemcpyHostToDevice, sin);
+                if (e != hipSuccess) return e;
+            }
+        }
+        return piped ? hipEventRecord(h->ev_in[s], sin) : hipSuccess;
+    };
+    auto download = [&](int c) -> hipError_t {
+        const int s = c & 1, f0 = c * chunk, B = std::min(chunk, nframes - f0);
+        hipError_t e = piped ? hipStreamWaitEvent(sout, h->ev_done[s], 0) : hipSuccess;
+        if (e == hipSuccess) e = hipMemcpyAsync(kps + (int64_t)f0 * cap, h->st_kps[s], (size_t)B * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, sout);
+        if (e == hipSuccess) e = hipMemcpyAsync(desc + (int64_t)f0 * cap * 32, h->st_desc[s], (size_t)B * cap * 32, hipMemcpyDeviceToHost, sout);
+        if (e == hipSuccess) e = hipMemcpyAsync(counts + f0, h->st_cnt[s], (size_t)B * sizeof(int), hipMemcpyDeviceToHost, sout);
+        if (e == hipSuccess) e = hipMemcpyAsync(hstat.data() + (size_t)s * chunk, h->st_cnt[s] + chunk, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, sout);
+        if (e == hipSuccess) e = hipStreamSynchronize(sout);   // the staging set `s` is free again after this
+        if (e == hipSuccess)
+            for (int i = 0; i < B; ++i)
+                if (hstat[(size_t)s * chunk + i] != ORBX_OK) worst = (orbx_status)hstat[(size_t)s * chunk + i];
+        return e;
+    };
+    HIPCHK(upload(0));
+    for (int c = 0; c < nchunks; ++c) {
+        const int s = c & 1, f0 = c * chunk, B = std::min(chunk, nframes - f0);
+        if (piped) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_in[s], 0));
+        st = run_chunk(h, B, h->st_in[s], width, height, stride, (int64_t)fbytes, h->st_kps[s], h->st_desc[s], h->st_cnt[s],
+                       h->st_cnt[s] + chunk, cap);
+        if (st != ORBX_OK) { hipStreamSynchronize(h->stream); hipStreamSynchronize(sin); return st; }
+        if (piped) HIPCHK(hipEventRecord(h->ev_done[s], h->stream));
+        if (c + 1 < nchunks) HIPCHK(upload(c + 1));      // set (c+1)&1 was released by download(c-1) below
+        if (c >= 1) HIPCHK(download(c - 1));
     }
+    HIPCHK(download(nchunks - 1));
     if (worst != ORBX_OK) return fail(worst, "a frame exceeded the keypoint / candidate capacity");
     return ORBX_OK;
 }
