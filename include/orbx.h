@@ -331,6 +331,21 @@ orbx_status orbx_bow_vectors(const orbx_vocabulary *voc, const uint32_t *word_id
                              const uint32_t *node_id, int n, uint32_t *bow_word, double *bow_value, int *n_bow,
                              uint32_t *fv_node, int32_t *fv_begin, uint32_t *fv_index, int *n_fv_nodes);
 
+/* ---- Frame glue: Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:770-865) =
+ * cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) on the keypoint coordinates.  camera4 = fx, fy, cx, cy of mK;
+ * dist = mDistCoef (k1, k2, p1, p2[, k3], at most 14); dist[0] == 0 copies the keypoints unchanged (:772-776).  OpenCV 3.2
+ * arithmetic (double precision, five fixed iterations): parity unpinned, like every OpenCV-owned stage.  The device form
+ * works on the buffers orbx_extract_batch_device filled (records `cap` apart, counts per frame) so that the keypoints need
+ * not leave the GPU; AssignFeaturesToGrid stays orbx_grid_create (host, like the selection passes that read the grid). */
+orbx_status orbx_undistort_keypoints_device(orbx_handle *h, int nframes, const orbx_keypoint *d_kps, const int32_t *d_counts,
+                                            int cap, const float *camera4, const float *dist, int ndist,
+                                            orbx_keypoint *d_kps_un);
+orbx_status orbx_undistort_keypoints(orbx_handle *h, const orbx_keypoint *kps, int n, const float *camera4, const float *dist,
+                                     int ndist, orbx_keypoint *kps_un);
+/* mnMinX, mnMaxX, mnMinY, mnMaxY */
+orbx_status orbx_image_bounds(orbx_handle *h, int cols, int rows, const float *camera4, const float *dist, int ndist,
+                              float *bounds4);
+
 /* Page-locked host memory for the host-buffer entry points: with it every upload / download of orbx_extract_batch is an
  * asynchronous DMA that overlaps the kernels of the neighbouring chunks (pageable memory works too, the runtime then
  * stages the copies and blocks the calling thread while it does).  A call with more frames than the handle's max_batch is

@@ -172,6 +172,13 @@ int orc_bow_vectors(int weighting, int scoring, const uint32_t *word_id, const d
                     int n, uint32_t *bow_word, double *bow_value, int *n_bow, uint32_t *fv_node, int *fv_begin,
                     uint32_t *fv_index, int *n_fv_nodes);
 
+/* ---- Frame::UndistortKeyPoints / ComputeImageBounds: cv::undistortPoints(K, D, R = I, P = K), OpenCV 3.2 (parity unpinned) */
+void orc_undistort_points(const float *pts, int n, float fx, float fy, float cx, float cy, const float *dist, int ndist,
+                          float *out);
+void orc_undistort_keypoints(const orc_keypoint *k, int n, float fx, float fy, float cx, float cy, const float *dist,
+                             int ndist, orc_keypoint *out);
+void orc_image_bounds(int cols, int rows, float fx, float fy, float cx, float cy, const float *dist, int ndist, float *b4);
+
 #ifdef __cplusplus
 }
 #endif

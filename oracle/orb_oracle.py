@@ -106,6 +106,12 @@ def lib():
         L.orc_bow_transform.argtypes = [ci, ci] + [vp_] * 6 + [ci, ci] + [vp_] * 3
         L.orc_bow_vectors.restype = ci
         L.orc_bow_vectors.argtypes = [ci, ci, vp_, vp_, vp_, ci, vp_, vp_, vp_, vp_, vp_, vp_, vp_]
+        L.orc_undistort_points.restype = None
+        L.orc_undistort_points.argtypes = [vp_, ci, cf, cf, cf, cf, vp_, ci, vp_]
+        L.orc_undistort_keypoints.restype = None
+        L.orc_undistort_keypoints.argtypes = [vp_, ci, cf, cf, cf, cf, vp_, ci, vp_]
+        L.orc_image_bounds.restype = None
+        L.orc_image_bounds.argtypes = [ci, ci, cf, cf, cf, cf, vp_, ci, vp_]
         L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
@@ -434,3 +440,17 @@ def bow_transform(voc, desc, levelsup=4):
                           C.byref(nb), _p(fn), _p(fb), _p(fi), C.byref(nn))
     return (wid[:n].copy(), w[:n].copy(), nid[:n].copy(), (bw[:nb.value].copy(), bv[:nb.value].copy()),
             (fn[:nn.value].copy(), fb[:nn.value + 1].copy(), fi[:fb[nn.value]].copy()))
+
+
+def undistort_keypoints(kps, K, dist):
+    """Frame::UndistortKeyPoints; K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2[, k3])"""
+    k = np.ascontiguousarray(kps, KP_DTYPE); d = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros(max(len(k), 1), KP_DTYPE)
+    lib().orc_undistort_keypoints(_p(k), len(k), *[float(v) for v in K], _p(d), len(d), _p(out))
+    return out[:len(k)].copy()
+
+
+def image_bounds(cols, rows, K, dist):
+    d = np.ascontiguousarray(dist, np.float32); b = np.zeros(4, np.float32)
+    lib().orc_image_bounds(cols, rows, *[float(v) for v in K], _p(d), len(d), _p(b))
+    return b

@@ -899,3 +899,65 @@ int orc_bow_vectors(int weighting, int scoring, const uint32_t *word_id, const d
     free(cnt); free(tmp_idx); free(pn); free(pf);
     return nb;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Frame::UndistortKeyPoints (src/Frame.cc:770-825) / ComputeImageBounds (:830-865): cv::undistortPoints(src, dst, K, D,
+ * R = empty, P = K) on float points.  OpenCV boundary, PARITY UNPINNED: restated from OpenCV 3.2 imgproc/undistort.cpp
+ * (cvUndistortPoints): everything in double, five fixed iterations of the inverse distortion model, then P * (x, y, 1):
+ *   x0 = x = (u - cx) / fx  (as  (u - cx) * (1. / fx)),  y likewise
+ *   repeat 5:  r2 = x*x + y*y
+ *              icdist = (1 + ((k7*r2 + k6)*r2 + k5)*r2) / (1 + ((k4*r2 + k1)*r2 + k0)*r2)
+ *              dx = 2*k2*x*y + k3*(r2 + 2*x*x) + k8*r2 + k9*r2*r2 ;  dy = k2*(r2 + 2*y*y) + 2*k3*x*y + k10*r2 + k11*r2*r2
+ *              x = (x0 - dx)*icdist ; y = (y0 - dy)*icdist
+ *   xx = P00*x + P01*y + P02 ; yy = P10*x + P11*y + P12 ; ww = 1. / (P20*x + P21*y + P22) ; out = (float)(xx*ww), (float)(yy*ww)
+ * k = (k1, k2, p1, p2, k3, 0...) as ORB-SLAM2 passes them (mDistCoef has 4 or 5 entries); the tilt model (k12, k13) is the
+ * identity for zero tilt.  K: fx, fy, cx, cy (float, converted to double as cvConvert does).
+ * ---------------------------------------------------------------------------------------------- */
+void orc_undistort_points(const float *pts, int n, float fx, float fy, float cx, float cy, const float *dist, int ndist,
+                          float *out) {
+    double k[14] = {0};
+    for (int i = 0; i < ndist && i < 14; ++i) k[i] = (double)dist[i];
+    const double dfx = (double)fx, dfy = (double)fy, dcx = (double)cx, dcy = (double)cy;
+    const double ifx = 1. / dfx, ify = 1. / dfy;
+    for (int i = 0; i < n; ++i) {
+        double x = (double)pts[2 * i], y = (double)pts[2 * i + 1];
+        double x0 = x = (x - dcx) * ifx;
+        double y0 = y = (y - dcy) * ify;
+        for (int j = 0; j < 5; ++j) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = dfx * x + 0.0 * y + dcx, yy = 0.0 * x + dfy * y + dcy;
+        const double ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+        out[2 * i] = (float)(xx * ww);
+        out[2 * i + 1] = (float)(yy * ww);
+    }
+}
+/* mvKeysUn from mvKeys (identity copy when dist[0] == 0, :772-776) */
+void orc_undistort_keypoints(const orc_keypoint *k, int n, float fx, float fy, float cx, float cy, const float *dist,
+                             int ndist, orc_keypoint *out) {
+    for (int i = 0; i < n; ++i) out[i] = k[i];
+    if (ndist < 1 || dist[0] == 0.0f) return;
+    for (int i = 0; i < n; ++i) {
+        float p[2] = {k[i].x, k[i].y}, q[2];
+        orc_undistort_points(p, 1, fx, fy, cx, cy, dist, ndist, q);
+        out[i].x = q[0]; out[i].y = q[1];
+    }
+}
+/* ComputeImageBounds: (mnMinX, mnMaxX, mnMinY, mnMaxY) */
+void orc_image_bounds(int cols, int rows, float fx, float fy, float cx, float cy, const float *dist, int ndist, float *b4) {
+    if (ndist >= 1 && dist[0] != 0.0f) {
+        float p[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows}, q[8];
+        orc_undistort_points(p, 4, fx, fy, cx, cy, dist, ndist, q);
+        b4[0] = q[0] < q[4] ? q[0] : q[4];     /* min(x of top-left, x of bottom-left) */
+        b4[1] = q[2] > q[6] ? q[2] : q[6];
+        b4[2] = q[1] < q[3] ? q[1] : q[3];
+        b4[3] = q[5] > q[7] ? q[5] : q[7];
+    } else {
+        b4[0] = 0.0f; b4[1] = (float)cols; b4[2] = 0.0f; b4[3] = (float)rows;
+    }
+}

@@ -1317,3 +1317,62 @@ extern "C" orbx_status orbx_bow_vectors(const orbx_vocabulary *voc, const uint32
     *n_fv_nodes = nn;
     return ORBX_OK;
 }
+
+// ---------------------------------------------------------------- (f)2: Frame::UndistortKeyPoints / ComputeImageBounds
+// (src/Frame.cc:770-865): cv::undistortPoints(K, D, R = I, P = K) on the device (k_undistort).  camera4 = fx, fy, cx, cy
+// (mK), dist = mDistCoef (k1, k2, p1, p2[, k3 ...], up to 14).  dist[0] == 0 copies the keypoints (:772-776).
+static void undistort_args(const float *camera4, const float *dist, int ndist, double *K4, double *k14, int *identity) {
+    for (int i = 0; i < 4; ++i) K4[i] = (double)camera4[i];
+    for (int i = 0; i < 14; ++i) k14[i] = i < ndist ? (double)dist[i] : 0.0;
+    *identity = (ndist < 1 || dist[0] == 0.0f) ? 1 : 0;
+}
+extern "C" orbx_status orbx_undistort_keypoints_device(orbx_handle *h, int nframes, const orbx_keypoint *d_kps,
+                                                       const int32_t *d_counts, int cap, const float *camera4, const float *dist,
+                                                       int ndist, orbx_keypoint *d_kps_un) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (nframes <= 0 || cap <= 0 || !d_kps || !d_counts || !d_kps_un || !camera4 || ndist < 0 || ndist > 14 || (ndist > 0 && !dist))
+        return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    HIPCHK(hipSetDevice(h->dev));
+    double K4[4], k14[14]; int identity;
+    undistort_args(camera4, dist, ndist, K4, k14, &identity);
+    { ProfScope ps(h, ORBX_K_MISC);
+      orbx_launch_undistort(h->stream, nframes, cap, cap, K4, k14, identity, d_kps, d_counts, d_kps_un); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
+    return ORBX_OK;
+}
+extern "C" orbx_status orbx_undistort_keypoints(orbx_handle *h, const orbx_keypoint *kps, int n, const float *camera4,
+                                                const float *dist, int ndist, orbx_keypoint *kps_un) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (n < 0 || (n > 0 && (!kps || !kps_un)) || !camera4 || ndist < 0 || ndist > 14 || (ndist > 0 && !dist))
+        return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    if (n == 0) return ORBX_OK;
+    HIPCHK(hipSetDevice(h->dev));
+    orbx_status st = scratch_reserve(h, 2 * pad256((size_t)n * sizeof(orbx_keypoint)));
+    if (st != ORBX_OK) return st;
+    orbx_keypoint *din = scratch_take<orbx_keypoint>(h, n), *dout = scratch_take<orbx_keypoint>(h, n);
+    double K4[4], k14[14]; int identity;
+    undistort_args(camera4, dist, ndist, K4, k14, &identity);
+    HIPCHK(hipMemcpyAsync(din, kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, h->stream));
+    orbx_launch_undistort(h->stream, 1, n, n, K4, k14, identity, din, nullptr, dout);
+    HIPCHK(hipMemcpyAsync(kps_un, dout, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ORBX_OK;
+}
+// Frame::ComputeImageBounds (:830-865): the four image corners through the same kernel
+extern "C" orbx_status orbx_image_bounds(orbx_handle *h, int cols, int rows, const float *camera4, const float *dist, int ndist,
+                                         float *bounds4) {
+    if (!bounds4 || cols <= 0 || rows <= 0) return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    if (ndist < 1 || !dist || dist[0] == 0.0f) {
+        bounds4[0] = 0.0f; bounds4[1] = (float)cols; bounds4[2] = 0.0f; bounds4[3] = (float)rows;
+        return ORBX_OK;
+    }
+    orbx_keypoint c[4], u[4];
+    memset(c, 0, sizeof(c));
+    c[1].x = (float)cols; c[2].y = (float)rows; c[3].x = (float)cols; c[3].y = (float)rows;
+    const orbx_status st = orbx_undistort_keypoints(h, c, 4, camera4, dist, ndist, u);
+    if (st != ORBX_OK) return st;
+    bounds4[0] = std::min(u[0].x, u[2].x); bounds4[1] = std::max(u[1].x, u[3].x);
+    bounds4[2] = std::min(u[0].y, u[1].y); bounds4[3] = std::max(u[2].y, u[3].y);
+    return ORBX_OK;
+}

@@ -1715,6 +1715,39 @@ __global__ __launch_bounds__(256) void k_bow_transform(DVoc voc, const uint8_t *
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K10: Frame::UndistortKeyPoints (reference src/Frame.cc:770-825) = cv::undistortPoints(K, D, R = I, P = K) on the
+// keypoint coordinates (OpenCV 3.2 cvUndistortPoints: double precision, five fixed iterations; parity unpinned, see
+// oracle/orb_oracle_match.c).  One thread per keypoint, the other 20 bytes of the record are copied.
+// ------------------------------------------------------------------------------------------------
+struct DUndist { double fx, fy, cx, cy, k[14]; int identity; };
+__global__ __launch_bounds__(256) void k_undistort(DUndist u, const orbx_keypoint *__restrict__ kps, const int *__restrict__ counts,
+                                                   int fixed_n, int cap, orbx_keypoint *__restrict__ out) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n = counts ? min(counts[f], cap) : fixed_n;
+    if (i >= n) return;
+    orbx_keypoint kp = kps[(long long)f * cap + i];
+    if (!u.identity) {
+        const double ifx = 1. / u.fx, ify = 1. / u.fy;
+        double x = (double)kp.x, y = (double)kp.y;
+        const double x0 = x = (x - u.cx) * ifx;
+        const double y0 = y = (y - u.cy) * ify;
+        for (int j = 0; j < 5; ++j) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((u.k[7] * r2 + u.k[6]) * r2 + u.k[5]) * r2) / (1 + ((u.k[4] * r2 + u.k[1]) * r2 + u.k[0]) * r2);
+            const double deltaX = 2 * u.k[2] * x * y + u.k[3] * (r2 + 2 * x * x) + u.k[8] * r2 + u.k[9] * r2 * r2;
+            const double deltaY = u.k[2] * (r2 + 2 * y * y) + 2 * u.k[3] * x * y + u.k[10] * r2 + u.k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = u.fx * x + 0.0 * y + u.cx, yy = 0.0 * x + u.fy * y + u.cy;
+        const double ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+        kp.x = (float)(xx * ww);
+        kp.y = (float)(yy * ww);
+    }
+    out[(long long)f * cap + i] = kp;
+}
+
 __global__ void k_clear(int *a, int na, int *b, int nb, int *c, int nc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < na) a[i] = 0;
@@ -1785,6 +1818,15 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
     const int gpw = (long long)B * ngroups >= 16384 ? FR_GPW : 1;
     hipLaunchKernelGGL(k_fast_rows, dim3(B, (ngroups + gpw - 1) / gpw), dim3(64), smem, s, g, cells, groups, pyr, cand,
                        cell_count, max_ch, lcap, ngroups, gpw, dbg_stop);
+}
+void orbx_launch_undistort(hipStream_t s, int B, int max_n, int cap, const double *K4, const double *k14, int identity,
+                           const orbx_keypoint *kps, const int *counts, orbx_keypoint *out) {
+    if (B <= 0 || max_n <= 0) return;
+    DUndist u;
+    u.fx = K4[0]; u.fy = K4[1]; u.cx = K4[2]; u.cy = K4[3];
+    for (int i = 0; i < 14; ++i) u.k[i] = k14[i];
+    u.identity = identity;
+    hipLaunchKernelGGL(k_undistort, dim3((max_n + 255) / 256, B), dim3(256), 0, s, u, kps, counts, max_n, cap, out);
 }
 void orbx_launch_bow_transform(hipStream_t s, int B, int max_n, const int *child_begin, const uint32_t *child_ids,
                                const uint8_t *node_desc, int n_nodes, int L, const uint8_t *desc, const int *counts,

@@ -14,6 +14,8 @@ void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr, bool narrow);
 void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *groups,
                            int ngroups, const uint8_t *pyr, uint2 *cand, int *cell_count, int max_ch, int lcap, int dbg_stop);
+void orbx_launch_undistort(hipStream_t s, int B, int max_n, int cap, const double *K4, const double *k14, int identity,
+                           const orbx_keypoint *kps, const int *counts, orbx_keypoint *out);
 void orbx_launch_bow_transform(hipStream_t s, int B, int max_n, const int *child_begin, const uint32_t *child_ids,
                                const uint8_t *node_desc, int n_nodes, int L, const uint8_t *desc, const int *counts,
                                long long frame_stride, int levelsup, uint32_t *out_leaf, uint32_t *out_nid, int out_stride);

@@ -18,10 +18,24 @@ class Frame:
         self.mvKeysUn = self.mvKeys
         self.mDescriptors = np.ascontiguousarray(descriptors, np.uint8)
         self.N = len(self.mvKeys)
+        self._wh = (int(width), int(height))
         self.bounds = tuple(float(b) for b in (bounds or (0, width, 0, height)))
         self.mvuRight = np.full(self.N, -1.0, np.float32)
         self.mvDepth = np.full(self.N, -1.0, np.float32)
         self._grid = None
+
+    def UndistortKeyPoints(self, extractor, K, dist):
+        """Frame::UndistortKeyPoints + ComputeImageBounds (src/Frame.cc:770-865): K = (fx, fy, cx, cy), dist = mDistCoef.
+        Sets mvKeysUn and the grid bounds (the reference computes the bounds once per camera, :115-124)."""
+        k4 = np.ascontiguousarray(K, np.float32); d = np.ascontiguousarray(dist, np.float32)
+        out = np.zeros(max(self.N, 1), KP_DTYPE)
+        check(lib().orbx_undistort_keypoints(extractor.handle, ptr(self.mvKeys), self.N, ptr(k4), ptr(d), len(d), ptr(out)))
+        self.mvKeysUn = out[:self.N].copy()
+        b = np.zeros(4, np.float32)
+        check(lib().orbx_image_bounds(extractor.handle, self._wh[0], self._wh[1], ptr(k4), ptr(d), len(d), ptr(b)))
+        self.bounds = tuple(float(v) for v in b)
+        self._free()
+        return self.mvKeysUn
 
     def AssignFeaturesToGrid(self):
         self._free()
