@@ -477,10 +477,10 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         const DLevel &Ln = g.lv[c0_n.level];                                                                             \
         const int twn = c1_n.x0 + c1_n.cw - c0_n.x0;                                                                      \
         const int ndwn = ((c0_n.x0 & 3) + twn + 3) >> 2;                                                                  \
-        const uint8_t *srcn = pyr + (long long)f * g.pyr_bytes + Ln.off + (long long)c0_n.y0 * Ln.pitch + (c0_n.x0 & ~3) + \
-                              4 * min(dq, ndwn - 1);                                                                      \
-        _Pragma("unroll") for (int k = 0; k < 14; ++k)                                                                    \
-            tv[k] = *(const uint32_t *)(srcn + (long long)min(3 * k + rq, (int)c0_n.ch - 1) * Ln.pitch);                  \
+        const uint8_t *srcn = pyr + (long long)f * g.pyr_bytes + Ln.off + (__mul24((int)c0_n.y0, Ln.pitch) + (c0_n.x0 & ~3) + \
+                                                                             4 * min(dq, ndwn - 1));                      \
+        _Pragma("unroll") for (int k = 0; k < 14; ++k)   /* 24-bit row offsets: 64-bit multiplies are slow */               \
+            tv[k] = *(const uint32_t *)(srcn + __mul24(min(3 * k + rq, (int)c0_n.ch - 1), Ln.pitch));                     \
     }
     FR_PREFETCH()
   for (int gi = 0; gi < ng; ++gi) {
@@ -1112,6 +1112,8 @@ __device__ __attribute__((noinline)) OrbxSinCos orbx_sincosf_call(float y) { ret
 #ifndef DS_KPW
 #define DS_KPW 1
 #endif
+// FPM (fp_mode) is a template constant: as a run-time value it costs a scalar branch and both code paths in each of the 8 taps
+template <int FPM>
 __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
                                                   const uint32_t *__restrict__ lvl_kp,
                                                   const int *__restrict__ lvl_count,
@@ -1165,9 +1167,10 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
     {                                                                                                                     \
         DS_GEOM(K)                                                                                                        \
         if (interior) {                                                                                                   \
+            const uint8_t *p0 = img + (__mul24(py0, L.pitch) + xa + 4 * dq);   /* 32-bit offsets: no 64-bit multiplies */          \
             _Pragma("unroll") for (int k = 0; k < 9; ++k) {                                                               \
                 const int r = min(5 * k + rq, DS_W - 1);                                                                  \
-                tv[k] = lane0 < 60 ? *(const uint32_t *)(img + (long long)(py0 + r) * L.pitch + xa + 4 * dq) : 0u;         \
+                tv[k] = lane0 < 60 ? *(const uint32_t *)(p0 + __mul24(r, L.pitch)) : 0u;                                  \
             }                                                                                                             \
         }                                                                                                                 \
     }
@@ -1214,14 +1217,16 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
             int vals[ORBX_HALF_PATCH + 1];
 #pragma unroll
             for (int v = 0; v <= ORBX_HALF_PATCH; ++v) vals[v] = pc[u + sgn * v * DS_PP];
-            int m10 = lane < 31 ? u * vals[0] : 0, m01 = 0;
+            // (24-bit multiplies: v_mul_lo_u32, which the compiler picks for int * int, is a quarter-rate instruction)
+            int m10 = lane < 31 ? __mul24(u, vals[0]) : 0, m01 = 0;
 #pragma unroll
             for (int v = 1; v <= ORBX_HALF_PATCH; ++v) {
                 const int d = g.umax[v];
                 const int val = (u >= -d && u <= d) ? vals[v] : 0;
-                m10 += u * val;
-                m01 += sgn * v * val;
+                m10 += __mul24(u, val);
+                m01 += __mul24(v, val);
             }
+            m01 = lane < 32 ? m01 : -m01;   // sgn * sum(v * val)
             m10 = orbx_wave_sum(m10);
             m01 = orbx_wave_sum(m01);
             angle_deg = orbx_fast_atan2((float)m01, (float)m10);
@@ -1231,7 +1236,7 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
         // ---- row pass: h[r][c] for patch columns c+3 (c = 0..36 used); 4 outputs per item from 3 aligned dwords via
         // v_alignbyte + v_dot4_u32_u8 with the packed 8-bit kernel {18,34,49,55 | 49,34,18,0}
         for (int i = lane; i < DS_W * (DS_HC / 4); i += 64) {
-            const int r = i / (DS_HC / 4), q4 = i - r * (DS_HC / 4);
+            const int r = __mul24(i, 6554) >> 16, q4 = i - r * (DS_HC / 4);   // i / 10 for i < 16384
             const uint32_t *w = patch + r * (DS_PP / 4) + q4;
             const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
             const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24), KHI = 49u | (34u << 8) | (18u << 16);
@@ -1274,7 +1279,7 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
                 const float px = (float)(signed char)((pw4[r] >> (16 * s2)) & 0xff);
                 const float py = (float)(signed char)((pw4[r] >> (16 * s2 + 8)) & 0xff);
                 float fy, fx;
-                if (g.fp_mode == ORBX_FP_GCC_FMA) {
+                if (FPM == ORBX_FP_GCC_FMA) {
                     fy = __builtin_fmaf(px, b, py * a);     // vfmadd132ss: x*b + rn(y*a)
                     fx = __builtin_fmaf(px, a, -(py * b));  // vfmsub132ss: x*a - rn(y*b)
                 } else {
@@ -1283,7 +1288,7 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
                 }
                 const int iy = (int)__builtin_rintf(fy), ix = (int)__builtin_rintf(fx);
                 // blurred pixel (x+ix, y+iy): column pass over h rows (iy+21-3 .. iy+21+3), h column ix+18
-                const uint16_t *hp = hrow + (iy + DS_R - 3) * DS_HC + (ix + DS_R - 3);
+                const uint16_t *hp = hrow + __mul24(iy + DS_R - 3, DS_HC) + (ix + DS_R - 3);
                 const uint32_t r0 = hp[3 * DS_HC], r1 = (uint32_t)hp[2 * DS_HC] + hp[4 * DS_HC],
                                r2 = (uint32_t)hp[1 * DS_HC] + hp[5 * DS_HC], r3 = (uint32_t)hp[0] + hp[6 * DS_HC];
                 const uint32_t I = __umul24(55u, r0) + __umul24(49u, r1) + __umul24(34u, r2) + __umul24(18u, r3);   // < 2^24.01
@@ -1855,8 +1860,11 @@ void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *p
                           int *counts, int *status, int cap) {
     static int dbg_stop = -1;
     if (dbg_stop < 0) { const char *e = getenv("ORBX_DESC_STOP"); dbg_stop = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(k_describe, dim3(B, (g.kp_total + 4 * DS_KPW - 1) / (4 * DS_KPW)), dim3(256), 0, s, g, pyr, lvl_kp, lvl_count,
-                       lvl_angle, kps, desc, counts, status, cap, dbg_stop);
+    const dim3 grid(B, (g.kp_total + 4 * DS_KPW - 1) / (4 * DS_KPW));
+    if (g.fp_mode == ORBX_FP_GCC_FMA)
+        hipLaunchKernelGGL(k_describe<ORBX_FP_GCC_FMA>, grid, dim3(256), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
+    else
+        hipLaunchKernelGGL(k_describe<ORBX_FP_STRICT>, grid, dim3(256), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
 }
 size_t orbx_match_workspace_bytes(int npairs, int out_stride) { return (size_t)npairs * MT_SPLIT * out_stride * sizeof(uint2); }
 void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,
