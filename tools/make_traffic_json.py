@@ -23,7 +23,8 @@ def collect(path, counter):
     for fn in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
             if r["Counter_Name"] == counter:
-                agg[r["Kernel_Name"].split("(")[0].split("<")[0]].append(float(r["Counter_Value"]))
+                name = r["Kernel_Name"].split("(")[0].split("<")[0]           # template instances: "void k_describe<0>(...)"
+                agg[name[5:] if name.startswith("void ") else name].append(float(r["Counter_Value"]))
     return agg
 
 
