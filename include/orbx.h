@@ -108,6 +108,13 @@ orbx_status orbx_extract_batch_device(orbx_handle *h, int nframes, const uint8_t
 enum { ORBX_FMT_GRAY8 = 0, ORBX_FMT_RGB8 = 1, ORBX_FMT_BGR8 = 2, ORBX_FMT_RGBA8 = 3, ORBX_FMT_BGRA8 = 4 };
 orbx_status orbx_set_input_format(orbx_handle *h, int pixel_format);
 
+/* EuRoC rectification (reference Examples/Stereo/stereo_euroc.cc:126-194): cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR)
+ * with the CV_32F maps of cv::initUndistortRectifyMap is fused into level 0; the extract entry points then take the RAW
+ * image.  map_x / map_y: width x height floats, row major (M1l / M2l); raw and rectified images have the same size, as in
+ * the reference's EuRoC driver.  OpenCV 3.2 fixed-point arithmetic (5-bit fractions, 2^15 weights, border value 0): parity
+ * unpinned.  NULL, NULL switches it off.  8-bit gray input only. */
+orbx_status orbx_set_rectification(orbx_handle *h, const float *map_x, const float *map_y, int width, int height);
+
 /* ---- pyramid access: replaces the public member `mvImagePyramid` (include/ORBextractor.h:185),
  *      read by Frame::ComputeStereoMatches (src/Frame.cc:910,1040,1072,1079).  Valid until the next
  *      extract on this handle ("pyramid is overwritten every frame", include/ORBextractor.h:30-35). -- */

@@ -179,6 +179,10 @@ void orc_undistort_keypoints(const orc_keypoint *k, int n, float fx, float fy, f
                              int ndist, orc_keypoint *out);
 void orc_image_bounds(int cols, int rows, float fx, float fy, float cx, float cy, const float *dist, int ndist, float *b4);
 
+/* ---- cv::remap(INTER_LINEAR, CV_32FC1 maps, BORDER_CONSTANT 0) on 8-bit images: EuRoC rectification (parity unpinned) */
+void orc_remap_linear_u8(const uint8_t *src, int sw, int sh, int sstride, const float *mapx, const float *mapy, int dw,
+                         int dh, uint8_t *dst, int dstride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,8 @@ def lib():
         L.orc_undistort_keypoints.argtypes = [vp_, ci, cf, cf, cf, cf, vp_, ci, vp_]
         L.orc_image_bounds.restype = None
         L.orc_image_bounds.argtypes = [ci, ci, cf, cf, cf, cf, vp_, ci, vp_]
+        L.orc_remap_linear_u8.restype = None
+        L.orc_remap_linear_u8.argtypes = [vp_, ci, ci, ci, vp_, vp_, ci, ci, vp_, ci]
         L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
@@ -454,3 +456,12 @@ def image_bounds(cols, rows, K, dist):
     d = np.ascontiguousarray(dist, np.float32); b = np.zeros(4, np.float32)
     lib().orc_image_bounds(cols, rows, *[float(v) for v in K], _p(d), len(d), _p(b))
     return b
+
+
+def remap_linear(img, mapx, mapy):
+    """cv::remap(img, ., mapx, mapy, INTER_LINEAR) for an 8-bit image and float32 maps of the output size"""
+    img = np.ascontiguousarray(img, np.uint8); mx = np.ascontiguousarray(mapx, np.float32); my = np.ascontiguousarray(mapy, np.float32)
+    dh, dw = mx.shape
+    out = np.zeros((dh, dw), np.uint8)
+    lib().orc_remap_linear_u8(_p(img), img.shape[1], img.shape[0], img.strides[0], _p(mx), _p(my), dw, dh, _p(out), dw)
+    return out

@@ -961,3 +961,53 @@ void orc_image_bounds(int cols, int rows, float fx, float fy, float cx, float cy
         b4[0] = 0.0f; b4[1] = (float)cols; b4[2] = 0.0f; b4[3] = (float)rows;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * cv::remap(src, dst, map1 CV_32FC1, map2 CV_32FC1, INTER_LINEAR, BORDER_CONSTANT 0) for 8-bit single-channel images
+ * (reference Examples/Stereo/stereo_euroc.cc:183-194: rectification of both EuRoC images before the extractor).
+ * OpenCV boundary, PARITY UNPINNED: restated from OpenCV 3.2 imgproc/imgwarp.cpp:
+ *   sx = cvRound(map1 * 32), sy = cvRound(map2 * 32)            (INTER_TAB_SIZE = 32; round half to even)
+ *   ix = saturate_cast<short>(sx >> 5), iy likewise, fx = sx & 31, fy = sy & 31
+ *   weights = BilinearTab_i[fy * 32 + fx] : saturate_cast<short>((1 - fy/32)(1 - fx/32) * 32768) etc. -- exact integers
+ *             (32 - fx)(32 - fy) * 32 ..., except the entry fx = fy = 0: 32768 saturates to 32767 and initInterTab2D's
+ *             residue correction puts the missing 1 on the [1][1] tap: {32767, 0, 0, 1}
+ *   dst = (w00*S[iy][ix] + w01*S[iy][ix+1] + w10*S[iy+1][ix] + w11*S[iy+1][ix+1] + (1 << 14)) >> 15, taps outside the
+ *         source read the border value 0.
+ * ---------------------------------------------------------------------------------------------- */
+static short orc_sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+void orc_remap_linear_u8(const uint8_t *src, int sw, int sh, int sstride, const float *mapx, const float *mapy, int dw,
+                         int dh, uint8_t *dst, int dstride) {
+    static short tab[32 * 32][4];
+    static int init = 0;
+    if (!init) {
+        for (int i = 0; i < 32; ++i)
+            for (int j = 0; j < 32; ++j) {
+                const float vy[2] = {1.f - i * (1.f / 32), i * (1.f / 32)}, vx[2] = {1.f - j * (1.f / 32), j * (1.f / 32)};
+                short *t = tab[i * 32 + j];
+                int isum = 0;
+                for (int k1 = 0; k1 < 2; ++k1)
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const float v = vy[k1] * vx[k2] * 32768.f;
+                        t[k1 * 2 + k2] = orc_sat_short((int)lrintf(v));
+                        isum += t[k1 * 2 + k2];
+                    }
+                if (isum != 32768) t[3] = (short)(t[3] - (isum - 32768));   /* only (0, 0): {32767, 0, 0, 1} */
+            }
+        init = 1;
+    }
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x) {
+            const int sx = (int)lrintf(mapx[(size_t)y * dw + x] * 32.f), sy = (int)lrintf(mapy[(size_t)y * dw + x] * 32.f);
+            const int ix = orc_sat_short(sx >> 5), iy = orc_sat_short(sy >> 5);
+            const short *w = tab[(sy & 31) * 32 + (sx & 31)];
+            int acc = 0;
+            for (int k1 = 0; k1 < 2; ++k1)
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int xx = ix + k2, yy = iy + k1;
+                    const int p = (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? src[(size_t)yy * sstride + xx] : 0;
+                    acc += w[k1 * 2 + k2] * p;
+                }
+            const int v = (acc + (1 << 14)) >> 15;
+            dst[(size_t)y * dstride + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+}

@@ -92,7 +92,7 @@ SYMBOLS = [
     "orbx_search_by_projection_mappoints", "orbx_set_input_format", "orbx_search_by_bow_keyframe_frame",
     "orbx_search_by_bow_keyframes", "orbx_search_for_triangulation", "orbx_fuse", "orbx_fuse_sim3",
     "orbx_search_by_projection_sim3", "orbx_search_by_sim3", "orbx_search_by_projection_keyframe",
-    "orbx_stereo_match_batch_device", "orbx_host_alloc", "orbx_host_free", "orbx_undistort_keypoints_device",
+    "orbx_stereo_match_batch_device", "orbx_host_alloc", "orbx_host_free", "orbx_set_rectification", "orbx_undistort_keypoints_device",
     "orbx_undistort_keypoints", "orbx_image_bounds", "orbx_vocabulary_create", "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_bow_transform_device", "orbx_bow_vectors",
 ]
 
@@ -189,6 +189,7 @@ def lib():
     L.orbx_undistort_keypoints_device.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, vp]
     L.orbx_undistort_keypoints.restype = i32; L.orbx_undistort_keypoints.argtypes = [vp, vp, i32, vp, vp, i32, vp]
     L.orbx_image_bounds.restype = i32; L.orbx_image_bounds.argtypes = [vp, i32, i32, vp, vp, i32, vp]
+    L.orbx_set_rectification.restype = i32; L.orbx_set_rectification.argtypes = [vp, vp, vp, i32, i32]
     L.orbx_host_alloc.restype = vp; L.orbx_host_alloc.argtypes = [C.c_size_t]
     L.orbx_host_free.restype = None; L.orbx_host_free.argtypes = [vp]
     _lib = L

@@ -63,6 +63,7 @@ struct orbx_handle {
     // grow-only scratch arena for the host-buffer convenience entry points (match / matrix / stereo): no hipMalloc
     // on the steady-state path and nothing to leak on an error return
     uint8_t *d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
+    uint2 *d_rect = nullptr; int rect_w = 0, rect_h = 0;   // pre-digested rectification maps (orbx_set_rectification)
     int input_format = ORBX_FMT_GRAY8;        // pixel format of the frames handed to the extract entry points
     bool blur_valid = false;                // d_blur holds the blurred pyramid of the last batch
     // profiling
@@ -267,7 +268,7 @@ extern "C" void orbx_destroy(orbx_handle *h) {
         prof_drain(h);
         for (auto e : h->pool) hipEventDestroy(e);
         free_geometry_buffers(h);
-        hipFree(h->d_match_ws); hipFree(h->d_scratch);
+        hipFree(h->d_match_ws); hipFree(h->d_scratch); hipFree(h->d_rect);
         for (int s = 0; s < 2; ++s) {
             hipFree(h->st_in[s]); hipFree(h->st_kps[s]); hipFree(h->st_desc[s]); hipFree(h->st_cnt[s]);
             if (h->ev_in[s]) hipEventDestroy(h->ev_in[s]);
@@ -316,9 +317,33 @@ extern "C" int orbx_max_keypoints(orbx_handle *h, int width, int height) {
 
 // ---------------------------------------------------------------- extraction
 static inline int orbx_fmt_channels(int fmt) { return fmt == ORBX_FMT_GRAY8 ? 1 : (fmt == ORBX_FMT_RGB8 || fmt == ORBX_FMT_BGR8) ? 3 : 4; }
+// cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) of Examples/Stereo/stereo_euroc.cc:183-194 in front of the extractor:
+// the float maps are digested once (cvRound(map * 32), split into integer part and 5-bit fractions, as remap() does per
+// block) and level 0 samples the raw image through them.  NULL maps switch the rectification off.
+extern "C" orbx_status orbx_set_rectification(orbx_handle *h, const float *map_x, const float *map_y, int width, int height) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(h->d_rect); h->d_rect = nullptr; h->rect_w = h->rect_h = 0;
+    if (!map_x && !map_y) return ORBX_OK;
+    if (!map_x || !map_y || width <= 0 || height <= 0) return fail(ORBX_BAD_ARGUMENT, "bad rectification maps");
+    if (h->input_format != ORBX_FMT_GRAY8) return fail(ORBX_BAD_ARGUMENT, "rectification needs 8-bit gray input");
+    std::vector<uint2> t((size_t)width * height);
+    for (size_t i = 0; i < t.size(); ++i) {
+        const int sx = (int)lrintf(map_x[i] * 32.f), sy = (int)lrintf(map_y[i] * 32.f);   // cvRound: half to even
+        const int ix = std::min(std::max(sx >> 5, -32768), 32767), iy = std::min(std::max(sy >> 5, -32768), 32767);
+        t[i].x = (uint32_t)(uint16_t)(int16_t)ix | ((uint32_t)(uint16_t)(int16_t)iy << 16);
+        t[i].y = (uint32_t)(((sy & 31) << 5) | (sx & 31));
+    }
+    HIPCHK(hipMalloc(&h->d_rect, t.size() * sizeof(uint2)));
+    HIPCHK(hipMemcpy(h->d_rect, t.data(), t.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    h->rect_w = width; h->rect_h = height;
+    return ORBX_OK;
+}
 extern "C" orbx_status orbx_set_input_format(orbx_handle *h, int pixel_format) {
     if (!h) return fail(ORBX_BAD_ARGUMENT, "null handle");
     if (pixel_format < ORBX_FMT_GRAY8 || pixel_format > ORBX_FMT_BGRA8) return fail(ORBX_BAD_ARGUMENT, "unknown pixel format");
+    if (h->d_rect && pixel_format != ORBX_FMT_GRAY8) return fail(ORBX_BAD_ARGUMENT, "rectification needs 8-bit gray input");
     h->input_format = pixel_format;
     return ORBX_OK;
 }
@@ -328,13 +353,17 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
     const DGeom &g = h->dg;
     hipStream_t s = h->stream;
     const int NL = g.nlevels;
+    if (h->d_rect && (h->rect_w != W || h->rect_h != H))
+        return fail(ORBX_BAD_ARGUMENT, "rectification maps were set for another image size (raw and rectified size must agree)");
     { ProfScope ps(h, ORBX_K_MISC);
       orbx_launch_clear(s, h->d_cand_count, B * NL, h->d_lvl_count, B * NL, d_status, B); }
     // (A two-stream level pipeline -- FAST of level l on a low-priority stream while the main stream resizes level
     // l+1 -- was measured and rejected: 81 k frames/s against 116 k for this single in-order sequence; the cross-stream
     // event waits and the 8 small FAST launches cost more than the overlap recovers.)
     { ProfScope ps(h, ORBX_K_PYR_L0);
-      if (h->input_format == ORBX_FMT_GRAY8) {
+      if (h->d_rect) {   // cv::remap of the EuRoC rectification fused into level 0
+          orbx_launch_pyr_l0_remap(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, h->d_rect);
+      } else if (h->input_format == ORBX_FMT_GRAY8) {
           orbx_launch_pyr_l0(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr);
       } else {   // cvtColor of Tracking::GrabImage* fused into level 0
           const int nch = (h->input_format == ORBX_FMT_RGB8 || h->input_format == ORBX_FMT_BGR8) ? 3 : 4;

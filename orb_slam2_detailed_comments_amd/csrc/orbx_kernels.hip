@@ -91,6 +91,44 @@ __global__ __launch_bounds__(256) void k_pyr_l0_color(DGeom g, const uint8_t *__
     *(uint32_t *)(pyr + (long long)f * g.pyr_bytes + L.off + (long long)Y * L.pitch + X) = v;
 }
 
+// cv::remap(INTER_LINEAR, float maps) of the EuRoC rectification (reference Examples/Stereo/stereo_euroc.cc:183-194)
+// fused into the border kernel: padded pixel P of level 0 = rectified pixel at reflect101(P - 19), and a rectified pixel is
+// the 5-bit fixed-point bilinear sample of the RAW image the host pre-digested map entry names (OpenCV 3.2 arithmetic:
+// weights (32-fx)(32-fy)*32 ... summing to 2^15, + 2^14, >> 15; taps outside the raw image read 0).  The fx = fy = 0 entry of
+// OpenCV's table is {32767, 0, 0, 1}: for 8-bit data that gives the same value as {32768, 0, 0, 0} (oracle keeps it literal).
+// rect entry: .x = ix | iy << 16 (int16 each), .y = fy << 5 | fx.  thread = 4 padded pixels.
+__global__ __launch_bounds__(256) void k_pyr_l0_remap(DGeom g, const uint8_t *__restrict__ imgs, int W, int H, int stride,
+                                                      long long frame_stride, uint8_t *__restrict__ pyr,
+                                                      const uint2 *__restrict__ rect) {
+    const DLevel &L = g.lv[0];
+    const int X = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int Y = blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (X >= L.pw || Y >= L.ph) return;
+    const uint8_t *src = imgs + (long long)f * frame_stride;
+    const uint2 *mrow = rect + (long long)orbx_reflect101(Y - ORBX_EDGE, H) * W;
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = X + i;
+        uint32_t p = 0;
+        if (x < L.pw) {
+            const uint2 m = mrow[orbx_reflect101(x - ORBX_EDGE, W)];
+            const int ix = (int)(short)(m.x & 0xffffu), iy = (int)(short)(m.x >> 16);
+            const uint32_t fx = m.y & 31u, fy = (m.y >> 5) & 31u;
+            const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W, y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
+            const uint8_t *r0 = src + (long long)iy * stride + ix, *r1 = r0 + stride;
+            const uint32_t p00 = (x0 && y0) ? r0[0] : 0u, p01 = (x1 && y0) ? r0[1] : 0u, p10 = (x0 && y1) ? r1[0] : 0u,
+                           p11 = (x1 && y1) ? r1[1] : 0u;
+            const uint32_t acc = __umul24((32u - fx) * (32u - fy) * 32u, p00) + __umul24(fx * (32u - fy) * 32u, p01) +
+                                 __umul24((32u - fx) * fy * 32u, p10) + __umul24(fx * fy * 32u, p11);
+            p = (acc + (1u << 14)) >> 15;
+        }
+        v |= p << (8 * i);
+    }
+    *(uint32_t *)(pyr + (long long)f * g.pyr_bytes + L.off + (long long)Y * L.pitch + X) = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: level l = cv::resize(INTER_LINEAR) of the PADDED level l-1 into the centre + reflect-101 border,
 // in one pass: the border is produced by evaluating the bilinear formula at the reflected coordinate
@@ -1798,6 +1836,12 @@ void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_
     const DLevel &L = g.lv[0];
     dim3 grid((L.pw + 255) / 256, (L.ph + 3) / 4, B);
     hipLaunchKernelGGL(k_pyr_l0_color, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, nch, r_off, b_off);
+}
+void orbx_launch_pyr_l0_remap(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
+                              long long frame_stride, uint8_t *pyr, const uint2 *rect) {
+    const DLevel &L = g.lv[0];
+    dim3 grid((L.pw + 255) / 256, (L.ph + 3) / 4, B);
+    hipLaunchKernelGGL(k_pyr_l0_remap, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, rect);
 }
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr, bool narrow) {
     const DLevel &L = g.lv[level];

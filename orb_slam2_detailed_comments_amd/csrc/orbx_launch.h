@@ -11,6 +11,8 @@ void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *img
                         long long frame_stride, uint8_t *pyr);
 void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
                               long long frame_stride, uint8_t *pyr, int nch, int r_off, int b_off);
+void orbx_launch_pyr_l0_remap(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
+                              long long frame_stride, uint8_t *pyr, const uint2 *rect);
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr, bool narrow);
 void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *groups,
                            int ngroups, const uint8_t *pyr, uint2 *cand, int *cell_count, int max_ch, int lcap, int dbg_stop);

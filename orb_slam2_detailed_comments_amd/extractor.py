@@ -114,6 +114,16 @@ class ORBextractor:
                                          ptr(desc), ptr(counts), cap))
         return [(kps[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(b)]
 
+    def set_rectification(self, map_x=None, map_y=None):
+        """cv::remap(., M1, M2, INTER_LINEAR) of the EuRoC driver fused into level 0 (float32 maps of the image size);
+        None, None switches it off"""
+        if map_x is None:
+            check(self._L.orbx_set_rectification(self._h, None, None, 0, 0))
+            return
+        mx, my = np.ascontiguousarray(map_x, np.float32), np.ascontiguousarray(map_y, np.float32)
+        assert mx.shape == my.shape and mx.ndim == 2
+        check(self._L.orbx_set_rectification(self._h, ptr(mx), ptr(my), mx.shape[1], mx.shape[0]))
+
     def extract_batch_device(self, d_imgs, nframes, width, height, stride, frame_stride, d_kps, d_desc, d_counts,
                              d_status, cap):
         """device-pointer entry (torch tensors or raw addresses); asynchronous on the handle's stream"""
