@@ -1127,6 +1127,10 @@ __global__ __launch_bounds__(256) void k_blur(DGeom g, const uint8_t *__restrict
 // ------------------------------------------------------------------------------------------------
 // pattern rearranged per lane: entry l holds, for round r = 0..3, the pair r*64 + l as (x1, y1, x2, y2) int8
 __constant__ int4 c_pattern_lane[64];
+// IC_Angle weights (orbx_upload_pattern): lane = (disc row v + 15) * 2 + half; per lane the 5 aligned dwords of the LDS patch
+// row it covers, as byte weights for v_dot4_u32_u8: [0..4] = u + 16 inside the disc (|u| <= umax[|v|]) else 0, [5..9] = 1
+// inside the disc else 0.  m10 = sum(u * I) = dot(I, u + 16) - 16 * dot(I, 1), m01 = v * dot(I, 1): exact integers.
+__constant__ uint32_t c_orient_w[64][12];
 
 // The 7x7 Gaussian (reference :2039-2047) is fused in: only a 43x43 neighbourhood of each keypoint is ever sampled
 // (|tap| <= 18, +3 px filter support), so each wave stages that patch of the UN-blurred level in LDS, runs the
@@ -1249,22 +1253,18 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
         // take the row +v, lanes 32-63 the row -v; integer moments reduced across the wave; fastAtan2 on every lane
         float angle_deg;
         {
-            const uint8_t *pc = (const uint8_t *)patch + DS_R * DS_PP + DS_R;   // the keypoint itself
-            const int u = (lane & 31) - ORBX_HALF_PATCH;                        // -15..16
-            const int sgn = lane < 32 ? 1 : -1;
-            int vals[ORBX_HALF_PATCH + 1];
-#pragma unroll
-            for (int v = 0; v <= ORBX_HALF_PATCH; ++v) vals[v] = pc[u + sgn * v * DS_PP];
-            // (24-bit multiplies: v_mul_lo_u32, which the compiler picks for int * int, is a quarter-rate instruction)
-            int m10 = lane < 31 ? __mul24(u, vals[0]) : 0, m01 = 0;
-#pragma unroll
-            for (int v = 1; v <= ORBX_HALF_PATCH; ++v) {
-                const int d = g.umax[v];
-                const int val = (u >= -d && u <= d) ? vals[v] : 0;
-                m10 += __mul24(u, val);
-                m01 += __mul24(v, val);
-            }
-            m01 = lane < 32 ? m01 : -m01;   // sgn * sum(v * val)
+            // lane = (row, half): 5 aligned dwords of patch row 21 + v, two v_dot4_u32_u8 each against the constant weights
+            const int row = lane >> 1, half = lane & 1;                 // row = v + 15 (lanes 62, 63 carry zero weights)
+            const uint32_t *pr = patch + min(row + (DS_R - ORBX_HALF_PATCH), DS_W - 1) * (DS_PP / 4) + 1 + 5 * half;
+            const uint4 wa = *(const uint4 *)&c_orient_w[lane][0], wb = *(const uint4 *)&c_orient_w[lane][4], wc = *(const uint4 *)&c_orient_w[lane][8];
+            const uint32_t p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3], p4 = pr[4];
+            uint32_t A = __builtin_amdgcn_udot4(p0, wa.x, 0u, false), S = __builtin_amdgcn_udot4(p0, wb.y, 0u, false);
+            A = __builtin_amdgcn_udot4(p1, wa.y, A, false); S = __builtin_amdgcn_udot4(p1, wb.z, S, false);
+            A = __builtin_amdgcn_udot4(p2, wa.z, A, false); S = __builtin_amdgcn_udot4(p2, wb.w, S, false);
+            A = __builtin_amdgcn_udot4(p3, wa.w, A, false); S = __builtin_amdgcn_udot4(p3, wc.x, S, false);
+            A = __builtin_amdgcn_udot4(p4, wb.x, A, false); S = __builtin_amdgcn_udot4(p4, wc.y, S, false);
+            int m10 = (int)A - 16 * (int)S;
+            int m01 = __mul24(row - ORBX_HALF_PATCH, (int)S);
             m10 = orbx_wave_sum(m10);
             m01 = orbx_wave_sum(m01);
             angle_deg = orbx_fast_atan2((float)m01, (float)m10);
@@ -1810,7 +1810,29 @@ hipError_t orbx_upload_pattern() {
     for (int l = 0; l < 64; ++l)
         for (int r = 0; r < 4; ++r)
             for (int k = 0; k < 4; ++k) t[l * 16 + r * 4 + k] = ORBX_PATTERN_I8[(r * 64 + l) * 4 + k];
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_pattern_lane), t, sizeof(t));
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern_lane), t, sizeof(t));
+    if (e != hipSuccess) return e;
+    // IC_Angle weight table: umax of the reference's constructor (src/ORBextractor.cc:866-910) for HALF_PATCH_SIZE = 15
+    orbx_params p;
+    orbx_default_params(&p);
+    OrbxTables tab;
+    orbx_build_tables(p, tab);
+    static uint32_t w[64][12];
+    memset(w, 0, sizeof(w));
+    for (int lane = 0; lane < 62; ++lane) {
+        const int row = lane >> 1, half = lane & 1, v = row - ORBX_HALF_PATCH;
+        const int d = tab.umax[v < 0 ? -v : v];
+        for (int k = 0; k < 5; ++k)
+            for (int b = 0; b < 4; ++b) {
+                const int col = 4 * (1 + 5 * half + k) + b;      // byte column inside the 44-byte LDS patch row
+                const int u = col - DS_R;
+                if (col < DS_W && u >= -d && u <= d) {
+                    w[lane][k] |= (uint32_t)(u + 16) << (8 * b);
+                    w[lane][5 + k] |= 1u << (8 * b);
+                }
+            }
+    }
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_orient_w), w, sizeof(w));
 }
 
 size_t orbx_quadtree_smem(int ncap, int lds_keys) {
