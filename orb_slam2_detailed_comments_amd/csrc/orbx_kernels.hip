@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
                                                   int *__restrict__ status, int cap, int dbg_stop) {
     // dbg_stop (ORBX_DESC_STOP, timing experiments only): 1 = after staging, 2 = after orientation, 3 = after the row pass
     __shared__ uint32_t s_patch[4][DS_W * DS_PP / 4 + 4];
-    __shared__ __attribute__((aligned(8))) uint16_t s_h[4][DS_W * DS_HC];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[4][DS_W * DS_HC];
     const int lane0 = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     const int f = blockIdx.x;   // frame fastest: one frame's patches stay in one XCD's L2
     // A wave takes DS_KPW consecutive OUTPUT indices (level-major order of operator(), :2066-2082): the staging of a
@@ -1273,21 +1273,29 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
         if (dbg_stop == 2) continue;
         // ---- row pass: h[r][c] for patch columns c+3 (c = 0..36 used); 4 outputs per item from 3 aligned dwords via
         // v_alignbyte + v_dot4_u32_u8 with the packed 8-bit kernel {18,34,49,55 | 49,34,18,0}
-        for (int i = lane; i < DS_W * (DS_HC / 4); i += 64) {
-            const int r = __mul24(i, 6554) >> 16, q4 = i - r * (DS_HC / 4);   // i / 10 for i < 16384
-            const uint32_t *w = patch + r * (DS_PP / 4) + q4;
-            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        for (int i = lane; i < DS_W * (DS_HC / 8); i += 64) {
+            // item = 8 consecutive outputs of one row from 4 aligned dwords: the byte-shifted middle dwords are shared
+            // between the two groups of four (9 v_alignbyte + 16 v_dot4 per 8 outputs)
+            const int r = __mul24(i, 13108) >> 16, q8 = i - r * (DS_HC / 8);   // i / 5 for i < 16384
+            const uint32_t *w = patch + r * (DS_PP / 4) + 2 * q8;
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
             const uint32_t KLO = 18u | (34u << 8) | (49u << 16) | (55u << 24), KHI = 49u | (34u << 8) | (18u << 16);
-            uint32_t hv[4];
+            uint32_t hv[8];
             hv[0] = __builtin_amdgcn_udot4(w0, KLO, __builtin_amdgcn_udot4(w1, KHI, 0u, false), false);
+            hv[4] = __builtin_amdgcn_udot4(w1, KLO, __builtin_amdgcn_udot4(w2, KHI, 0u, false), false);
 #pragma unroll
-            for (int j = 1; j < 4; ++j)
-                hv[j] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, j), KLO,
-                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, j), KHI, 0u, false), false);
-            uint2 o;
+            for (int j = 1; j < 4; ++j) {
+                const uint32_t a01 = __builtin_amdgcn_alignbyte(w1, w0, j), a12 = __builtin_amdgcn_alignbyte(w2, w1, j),
+                               a23 = __builtin_amdgcn_alignbyte(w3, w2, j);
+                hv[j] = __builtin_amdgcn_udot4(a01, KLO, __builtin_amdgcn_udot4(a12, KHI, 0u, false), false);
+                hv[4 + j] = __builtin_amdgcn_udot4(a12, KLO, __builtin_amdgcn_udot4(a23, KHI, 0u, false), false);
+            }
+            uint4 o;
             o.x = hv[0] | (hv[1] << 16);   // each <= 255 * 257 = 65535
             o.y = hv[2] | (hv[3] << 16);
-            *(uint2 *)(hrow + r * DS_HC + 4 * q4) = o;
+            o.z = hv[4] | (hv[5] << 16);
+            o.w = hv[6] | (hv[7] << 16);
+            *(uint4 *)(hrow + r * DS_HC + 8 * q8) = o;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
