@@ -45,7 +45,7 @@ def algorithmic_bytes(ex, w, h, n_kp):
     return {
         "k_pyr_l0": w * h + P[0],
         "k_pyr_resize": (Pt - P[-1]) + (Pt - P[0]),
-        "k_fast_cells": Pt,
+        "k_fast_rows": Pt,
         "k_quadtree": 0,
         "k_orient": n_kp * 749,
         "k_blur": 0,                                   # fused into k_describe (the blurred image is never written)

@@ -16,7 +16,7 @@ assert KP_DTYPE.itemsize == 28
 OK, EMPTY_IMAGE, BAD_ARGUMENT, BAD_ASPECT, CAPACITY, HIP_ERROR, NO_DEVICE, UNSUPPORTED = range(8)
 FP_GCC_FMA, FP_STRICT = 0, 1
 FMT_GRAY8, FMT_RGB8, FMT_BGR8, FMT_RGBA8, FMT_BGRA8 = range(5)
-K_NAMES = ("k_pyr_l0", "k_pyr_resize", "k_fast_cells", "k_quadtree", "k_orient", "k_blur", "k_describe",
+K_NAMES = ("k_pyr_l0", "k_pyr_resize", "k_fast_rows", "k_quadtree", "k_orient", "k_blur", "k_describe",
            "k_match", "misc")
 K_COUNT = len(K_NAMES)
 

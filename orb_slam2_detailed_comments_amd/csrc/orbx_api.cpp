@@ -78,7 +78,7 @@ struct orbx_handle {
 orbx_status orbx_fail(orbx_status s, const std::string &msg) { return fail(s, msg); }
 int orbx_handle_fp_mode(const orbx_handle *h) { return h->p.fp_mode; }
 
-static const char *k_names[ORBX_K_COUNT] = {"k_pyr_l0", "k_pyr_resize", "k_fast_cells", "k_quadtree", "k_orient",
+static const char *k_names[ORBX_K_COUNT] = {"k_pyr_l0", "k_pyr_resize", "k_fast_rows", "k_quadtree", "k_orient",
                                             "k_blur",   "k_describe",   "k_match",      "misc"};
 
 extern "C" const char *orbx_kernel_name(int k) { return (k >= 0 && k < ORBX_K_COUNT) ? k_names[k] : "?"; }

@@ -1141,19 +1141,12 @@ __constant__ uint32_t c_orient_w[64][12];
 #define DS_W (2 * DS_R + 1)     // 43
 #define DS_PP 44                // LDS patch pitch in bytes (11 dwords; rows start dword-aligned in LDS)
 #define DS_HC 40                // row-pass outputs per row (37 needed, computed in groups of 4)
-// a real call: inlined into the keypoint loop, the dozen double-precision constants of the polynomial are hoisted
-// out of the loop and pinned in 20+ VGPRs for the whole kernel
-__device__ __attribute__((noinline)) OrbxSinCos orbx_sincosf_call(float y) { return orbx_sincosf_pinned(y); }
 #ifndef DS_WPS
 #define DS_WPS 7   // waves per SIMD the register allocation must allow (LDS admits 7 blocks of 4 waves per CU)
 #endif
-// Keypoints per wave, one after the other with the next patch prefetched into registers.  Measured on MI355X (256 frames):
-// 1 -> 375 us, 2 / 4 / 8 at 4-5 waves per SIMD -> 430-440 us: every phase of this kernel is a dependent chain of LDS
-// round trips, so what hides latency is the number of resident waves, and the registers of the prefetch cost more
-// occupancy than the prefetch recovers.  The loop stays (DS_KPW is a build knob), the default is one keypoint per wave.
-#ifndef DS_KPW
-#define DS_KPW 1
-#endif
+// (Several keypoints per wave with register prefetch of the next patch was measured: 430-440 us at the 4-5 waves per
+// SIMD its registers allow against 375 us for one keypoint per wave -- every phase of this kernel is a dependent chain of
+// LDS round trips, and resident waves are what hides them.)
 // FPM (fp_mode) is a template constant: as a run-time value it costs a scalar branch and both code paths in each of the 8 taps
 template <int FPM>
 __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
@@ -1165,72 +1158,47 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
     // dbg_stop (ORBX_DESC_STOP, timing experiments only): 1 = after staging, 2 = after orientation, 3 = after the row pass
     __shared__ uint32_t s_patch[4][DS_W * DS_PP / 4 + 4];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[4][DS_W * DS_HC];
-    const int lane0 = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+    // one wave per keypoint, waves indexed by dense OUTPUT position (level-major order of operator(), :2066-2082).
+    // The wave index is wave-uniform (which the compiler cannot see): with it scalar, the level search and the position
+    // load run on the scalar unit.
+    const int lane = threadIdx.x & 63, wv_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int f = blockIdx.x;   // frame fastest: one frame's patches stay in one XCD's L2
-    // A wave takes DS_KPW consecutive OUTPUT indices (level-major order of operator(), :2066-2082): the staging of a
-    // patch is a chain of dependent global loads (position -> rows), so the rows of keypoint k+1 are requested
-    // before keypoint k is evaluated and land in registers while the wave computes.
-    const int o0 = (blockIdx.y * 4 + wv_id) * DS_KPW;
+    const int oi = blockIdx.y * 4 + wv_id;
     const int *lc = lvl_count + f * g.nlevels;
-    int total = 0;
-    // this lane's keypoint (lanes 0 .. DS_KPW-1): level / slot from the per-level counts
-    const int omine = o0 + lane0;
-    int lev_l = 0, slot_l = omine;
+    int total = 0, level = 0, slot = oi;
 #pragma unroll
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         if (l < g.nlevels) {
-            if (omine >= total) { lev_l = l; slot_l = g.lv[l].kp_begin + (omine - total); }
+            if (oi >= total) { level = l; slot = g.lv[l].kp_begin + (oi - total); }
             total += lc[l];
         }
     }
-    if (blockIdx.y == 0 && wv_id == 0 && lane0 == 0) {
+    if (blockIdx.y == 0 && wv_id == 0 && lane == 0) {
         counts[f] = min(total, cap);
         if (total > cap) atomicMax(&status[f], (int)ORBX_CAPACITY);
     }
-    const int nvalid = min(total, cap);
-    if (o0 >= nvalid) return;
-    const int nk = min(DS_KPW, nvalid - o0);
-    const uint32_t pos_l = lvl_kp[(long long)f * g.kp_total + min(slot_l, g.kp_total - 1)];
+    if (oi >= min(total, cap)) return;
+    const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];
+    const int4 pat = c_pattern_lane[lane];
     uint32_t *patch = s_patch[wv_id];
     uint16_t *hrow = s_h[wv_id];
-    const int dq = lane0 % 12, rq = lane0 / 12;   // staging: 5 rows x 12 aligned dwords per step
-    uint32_t tv[9];
-    // geometry of keypoint k (wave-uniform) and the request of its rows
-#define DS_GEOM(K)                                                                                                        \
-    const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)pos_l, K);                                               \
-    const int level = __builtin_amdgcn_readlane(lev_l, K);                                                                \
-    const DLevel &L = g.lv[level];                                                                                        \
-    const int x = (int)(pos & 0xfff) + (ORBX_EDGE - 3), y = (int)((pos >> 12) & 0xfff) + (ORBX_EDGE - 3);                 \
-    const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;                                                        \
-    const int px0 = x - DS_R, py0 = y - DS_R;                                                                             \
-    const int xa = px0 & ~3;                                                                                              \
+    const DLevel &L = g.lv[level];
+    const int x = (int)(pos & 0xfff) + (ORBX_EDGE - 3), y = (int)((pos >> 12) & 0xfff) + (ORBX_EDGE - 3);
+    const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;
+    const int px0 = x - DS_R, py0 = y - DS_R;
+    const int xa = px0 & ~3;
     const bool interior = px0 >= 0 && py0 >= 0 && xa + 48 <= L.pitch && x + DS_R < L.pw && y + DS_R < L.ph;
-#define DS_REQUEST(K)                                                                                                     \
-    {                                                                                                                     \
-        DS_GEOM(K)                                                                                                        \
-        if (interior) {                                                                                                   \
-            const uint8_t *p0 = img + (__mul24(py0, L.pitch) + xa + 4 * dq);   /* 32-bit offsets: no 64-bit multiplies */          \
-            _Pragma("unroll") for (int k = 0; k < 9; ++k) {                                                               \
-                const int r = min(5 * k + rq, DS_W - 1);                                                                  \
-                tv[k] = lane0 < 60 ? *(const uint32_t *)(p0 + __mul24(r, L.pitch)) : 0u;                                  \
-            }                                                                                                             \
-        }                                                                                                                 \
-    }
-    DS_REQUEST(0)
-#pragma unroll 1
-    for (int ki = 0; ki < nk; ++ki) {
-        // everything below is re-derived from an opaque copy of the lane id: otherwise the loop-invariant per-lane
-        // values (pattern floats, LDS offsets, constants) are hoisted out of the loop and cost ~100 registers
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
-        const int4 pat = c_pattern_lane[lane];
-        DS_GEOM(ki)
-        const int slot = __builtin_amdgcn_readlane(slot_l, ki);
-        const int oi = o0 + ki;
+    {
         // ---- stage the 43x43 patch (rows y-21.., columns x-21..): 12 ALIGNED dwords cover the 44 bytes of a patch
-        // row; dword d of the LDS row = funnel shift of aligned dwords d, d+1 (the neighbour lane's register, one DPP move)
+        // row; dword d of the LDS row = funnel shift of aligned dwords d, d+1 (the neighbour lane's register, one DPP
+        // move).  5 rows x 12 lanes per step, every load in flight before the first LDS write.
         if (interior) {
+            const int dq = lane % 12, rq = lane / 12;
             const uint32_t shift = (uint32_t)(px0 & 3);
+            const uint8_t *p0 = img + (__mul24(py0, L.pitch) + xa + 4 * dq);   // 32-bit offsets: no 64-bit multiplies
+            uint32_t tv[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) tv[k] = lane < 60 ? *(const uint32_t *)(p0 + __mul24(min(5 * k + rq, DS_W - 1), L.pitch)) : 0u;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const uint32_t nxt = orbx_lane_above(tv[k]);
@@ -1246,9 +1214,8 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
                 pb[r * DS_PP + c] = img[(long long)sy * L.pitch + sx];
             }
         }
-        if (ki + 1 < nk) DS_REQUEST(ki + 1)
         orbx_wave_sync();
-        if (dbg_stop == 1) continue;
+        if (dbg_stop == 1) return;
         // ---- orientation (IC_Angle, reference src/ORBextractor.cc:104-161) from the staged UN-blurred patch: lanes 0-31
         // take the row +v, lanes 32-63 the row -v; integer moments reduced across the wave; fastAtan2 on every lane
         float angle_deg;
@@ -1270,7 +1237,7 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
             angle_deg = orbx_fast_atan2((float)m01, (float)m10);
             if (lane == 0) lvl_angle[(long long)f * g.kp_total + slot] = angle_deg;
         }
-        if (dbg_stop == 2) continue;
+        if (dbg_stop == 2) return;
         // ---- row pass: h[r][c] for patch columns c+3 (c = 0..36 used); 4 outputs per item from 3 aligned dwords via
         // v_alignbyte + v_dot4_u32_u8 with the packed 8-bit kernel {18,34,49,55 | 49,34,18,0}
         for (int i = lane; i < DS_W * (DS_HC / 8); i += 64) {
@@ -1300,15 +1267,11 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (dbg_stop == 3) continue;
+        if (dbg_stop == 3) return;
         // ---- taps
         const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
         const float angle = angle_deg * factorPI;
-        #ifdef DS_SINCOS_CALL
-        const OrbxSinCos sc = orbx_sincosf_call(angle);
-#else
-        const OrbxSinCos sc = orbx_sincosf_pinned(angle);
-#endif
+                const OrbxSinCos sc = orbx_sincosf_pinned(angle);
         const float a = sc.c, b = sc.s;
         // Column pass at the tap position.  OpenCV's SSE2 column filter accumulates ((r0*k0 + r1*k1) + r2*k2) + r3*k3 in
         // float with k = {55,49,34,18}/65536 and rounds to nearest-even for the columns x < (w & ~3); the last w & 3
@@ -1361,10 +1324,7 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
             kp.class_id = -1;
             kps[(long long)f * cap + oi] = kp;
         }
-        orbx_wave_sync();   // the next keypoint overwrites patch / hrow
     }
-#undef DS_GEOM
-#undef DS_REQUEST
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1934,7 +1894,7 @@ void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *p
                           int *counts, int *status, int cap) {
     static int dbg_stop = -1;
     if (dbg_stop < 0) { const char *e = getenv("ORBX_DESC_STOP"); dbg_stop = e ? atoi(e) : 0; }
-    const dim3 grid(B, (g.kp_total + 4 * DS_KPW - 1) / (4 * DS_KPW));
+    const dim3 grid(B, (g.kp_total + 3) / 4);
     if (g.fp_mode == ORBX_FP_GCC_FMA)
         hipLaunchKernelGGL(k_describe<ORBX_FP_GCC_FMA>, grid, dim3(256), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
     else

@@ -243,7 +243,7 @@ def test_profile_counters():
     ex.profile_enable(0x1ff)
     ex.extract_batch(frames)
     p = ex.profile_read()
-    assert p["k_fast_cells"][1] == 1 and p["k_pyr_resize"][1] == 7 and p["k_describe"][0] > 0
+    assert p["k_fast_rows"][1] == 1 and p["k_pyr_resize"][1] == 7 and p["k_describe"][0] > 0
     assert p["k_blur"][1] == 0                      # the Gaussian is fused into k_describe
     ex.pyramid_level(0, 0, blur=True)               # ... and only materialised on request
     assert ex.profile_read()["k_blur"][1] == 1

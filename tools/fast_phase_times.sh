@@ -5,6 +5,6 @@ for s in 1 2 3 4 0; do
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
-        j = json.loads(line); print('stop', $s, 'k_fast ms/step', j['kernel_ms_per_step']['k_fast_cells'], 'fps', j['value'])
+        j = json.loads(line); print('stop', $s, 'k_fast ms/step', j['kernel_ms_per_step']['k_fast_rows'], 'fps', j['value'])
 "
 done

@@ -5,7 +5,7 @@ run() { # label, env...
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
-        j = json.loads(line); print('$label', 'k_fast', j['kernel_ms_per_step']['k_fast_cells'], 'fps', j['value'])
+        j = json.loads(line); print('$label', 'k_fast', j['kernel_ms_per_step']['k_fast_rows'], 'fps', j['value'])
 "
 }
 for v in "$@"; do run $v ORBX_LIB=$PWD/tools/bin/liborbx_$v.so; done

@@ -4,14 +4,14 @@
   tools/make_traffic_json.py FETCH_DIR WRITE_DIR OUT.json [batch width height nfeatures]
 
 HBM bytes per launch = FETCH_SIZE[KB] * 1024 * 2 (gfx950 calibration, tools/fetch_calib.hip) + WRITE_SIZE[KB] * 1024.
-Entries are keyed by the profiling slot bench.py uses (k_pyr_l0, k_pyr_resize, k_fast_cells, ...); the device kernels
-behind a slot are summed (k_fast_cells = k_fast_rows today, k_match = k_match + k_match_merge) and listed."""
+Entries are keyed by the profiling slot bench.py uses (k_pyr_l0, k_pyr_resize, k_fast_rows, ...); the device kernels
+behind a slot are summed (k_match = k_match + k_match_merge) and listed."""
 import csv, collections, glob, json, sys
 
 SLOTS = {
     "k_pyr_l0": ["k_pyr_l0", "k_pyr_l0_color"],
     "k_pyr_resize": ["k_pyr_resize", "k_pyr_resize_rows", "k_pyr_resize_flat"],
-    "k_fast_cells": ["k_fast_cells", "k_fast_rows"],
+    "k_fast_rows": ["k_fast_rows"],
     "k_quadtree": ["k_quadtree"],
     "k_describe": ["k_describe"],
     "k_match": ["k_match", "k_match_merge"],
