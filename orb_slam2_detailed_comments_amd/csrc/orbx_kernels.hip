@@ -1148,6 +1148,7 @@ __constant__ uint32_t c_orient_w[64][12];
 // SIMD its registers allow against 375 us for one keypoint per wave -- every phase of this kernel is a dependent chain of
 // LDS round trips, and resident waves are what hides them.)
 // FPM (fp_mode) is a template constant: as a run-time value it costs a scalar branch and both code paths in each of the 8 taps
+typedef const __attribute__((address_space(3))) uint16_t *orbx_lds_u16p;
 template <int FPM>
 __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
                                                   const uint32_t *__restrict__ lvl_kp,
@@ -1280,34 +1281,71 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
         // with I = 55 r0 + 49 r1 + 34 r2 + 18 r3: one integer formula serves both, the tail only changes the tie rule.
         const int wvec = L.pw & ~3;
         const int pw4[4] = {pat.x, pat.y, pat.z, pat.w};
-        int tval[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const float px = (float)(signed char)((pw4[r] >> (16 * s2)) & 0xff);
-                const float py = (float)(signed char)((pw4[r] >> (16 * s2 + 8)) & 0xff);
-                float fy, fx;
-                if (FPM == ORBX_FP_GCC_FMA) {
-                    fy = __builtin_fmaf(px, b, py * a);     // vfmadd132ss: x*b + rn(y*a)
-                    fx = __builtin_fmaf(px, a, -(py * b));  // vfmsub132ss: x*a - rn(y*b)
-                } else {
-                    fy = px * b + py * a;
-                    fx = px * a - py * b;
-                }
-                const int iy = (int)__builtin_rintf(fy), ix = (int)__builtin_rintf(fx);
-                // blurred pixel (x+ix, y+iy): column pass over h rows (iy+21-3 .. iy+21+3), h column ix+18
-                const uint16_t *hp = hrow + __mul24(iy + DS_R - 3, DS_HC) + (ix + DS_R - 3);
-                const uint32_t r0 = hp[3 * DS_HC], r1 = (uint32_t)hp[2 * DS_HC] + hp[4 * DS_HC],
-                               r2 = (uint32_t)hp[1 * DS_HC] + hp[5 * DS_HC], r3 = (uint32_t)hp[0] + hp[6 * DS_HC];
-                const uint32_t I = __umul24(55u, r0) + __umul24(49u, r1) + __umul24(34u, r2) + __umul24(18u, r3);   // < 2^24.01
-                const uint32_t tie = x + ix >= wvec ? 1u : ((I >> 16) & 1u);   // half-up in the tail, half-even elsewhere
-                tval[2 * r + s2] = (int)min((I + 0x7fffu + tie) >> 16, 255u);
-            }
-        }
         unsigned long long words[4];
+        if (x + (DS_R - 3) < wvec) {
+            // No tap of this keypoint reaches the tail columns (all but keypoints within 18 px of the right edge): the
+            // float form of round-half-even is the shortest.  cvRound of the rotated coordinates = adding 1.5 * 2^23
+            // (round-to-nearest-even in the add, the integer lands in the low mantissa bits); the 24-bit multiply-add
+            // takes those low bits as they are, the exponent bits of the column term cancel in the constant.
+            const uint32_t cbias = (uint32_t)(2 * ((DS_R - 3) * DS_HC + (DS_R - 3))) - 0x400000u * (2u * DS_HC) - (0x4B400000u << 1);
+            const uint32_t hbase = (uint32_t)(uintptr_t)(orbx_lds_u16p)hrow + cbias;
+            float tv[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) words[r] = orbx_ballot(tval[2 * r] < tval[2 * r + 1]);
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const float px = (float)(signed char)((pw4[r] >> (16 * s2)) & 0xff);
+                    const float py = (float)(signed char)((pw4[r] >> (16 * s2 + 8)) & 0xff);
+                    float fy, fx;
+                    if (FPM == ORBX_FP_GCC_FMA) {
+                        fy = __builtin_fmaf(px, b, py * a);     // vfmadd132ss: x*b + rn(y*a)
+                        fx = __builtin_fmaf(px, a, -(py * b));  // vfmsub132ss: x*a - rn(y*b)
+                    } else {
+                        fy = px * b + py * a;
+                        fx = px * a - py * b;
+                    }
+                    const uint32_t uy = __float_as_uint(fy + 12582912.0f), ux = __float_as_uint(fx + 12582912.0f);
+                    uint32_t adr = __umul24(uy, 2u * DS_HC) + ((ux << 1) + hbase);   // LDS byte address of h[iy+18][ix+18]
+                    asm("" : "+v"(adr));   // a plain address from here on: the row offsets fold into the ds_read immediates
+                    const orbx_lds_u16p hp = (orbx_lds_u16p)(uintptr_t)adr;
+                    const uint32_t r0 = hp[3 * DS_HC], r1 = (uint32_t)hp[2 * DS_HC] + hp[4 * DS_HC],
+                                   r2 = (uint32_t)hp[1 * DS_HC] + hp[5 * DS_HC], r3 = (uint32_t)hp[0] + hp[6 * DS_HC];
+                    const uint32_t I = __umul24(55u, r0) + __umul24(49u, r1) + __umul24(34u, r2) + __umul24(18u, r3);   // < 2^24.01
+                    // I <= 2^24 converts exactly and I * 2^-16 is exact; above, the conversion's own rounding keeps it >= 256
+                    tv[2 * r + s2] = __builtin_fminf(__builtin_rintf((float)I * (1.f / 65536.f)), 255.f);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) words[r] = orbx_ballot(tv[2 * r] < tv[2 * r + 1]);
+        } else {
+            int tval[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const float px = (float)(signed char)((pw4[r] >> (16 * s2)) & 0xff);
+                    const float py = (float)(signed char)((pw4[r] >> (16 * s2 + 8)) & 0xff);
+                    float fy, fx;
+                    if (FPM == ORBX_FP_GCC_FMA) {
+                        fy = __builtin_fmaf(px, b, py * a);
+                        fx = __builtin_fmaf(px, a, -(py * b));
+                    } else {
+                        fy = px * b + py * a;
+                        fx = px * a - py * b;
+                    }
+                    const int iy = (int)__builtin_rintf(fy), ix = (int)__builtin_rintf(fx);
+                    // blurred pixel (x+ix, y+iy): column pass over h rows (iy+21-3 .. iy+21+3), h column ix+18
+                    const uint16_t *hp = hrow + __mul24(iy + DS_R - 3, DS_HC) + (ix + DS_R - 3);
+                    const uint32_t r0 = hp[3 * DS_HC], r1 = (uint32_t)hp[2 * DS_HC] + hp[4 * DS_HC],
+                                   r2 = (uint32_t)hp[1 * DS_HC] + hp[5 * DS_HC], r3 = (uint32_t)hp[0] + hp[6 * DS_HC];
+                    const uint32_t I = __umul24(55u, r0) + __umul24(49u, r1) + __umul24(34u, r2) + __umul24(18u, r3);
+                    const uint32_t tie = x + ix >= wvec ? 1u : ((I >> 16) & 1u);   // half-up in the tail, half-even elsewhere
+                    tval[2 * r + s2] = (int)min((I + 0x7fffu + tie) >> 16, 255u);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) words[r] = orbx_ballot(tval[2 * r] < tval[2 * r + 1]);
+        }
         if (lane < 4) {
             unsigned long long w = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
             *(unsigned long long *)(desc + ((long long)f * cap + oi) * 32 + 8 * lane) = w;

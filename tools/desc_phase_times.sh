@@ -1,6 +1,6 @@
 #!/bin/bash
 for s in 1 2 3 0; do
-  ORBX_DESC_STOP=$s python bench.py --no-cpu-baseline --steps 8 --warmup 2 2>/dev/null | python -c "
+  ORBX_DESC_STOP=$s python bench.py --no-cpu-baseline --streams 1 --steps 8 --warmup 2 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # k_fast_rows time per phase: cumulative runs with ORBX_FAST_STOP (results are wrong for STOP != 0; timing only)
 for s in 1 2 3 4 0; do
-  ORBX_FAST_STOP=$s python bench.py --no-cpu-baseline --steps 8 --warmup 2 2>/dev/null | python -c "
+  ORBX_FAST_STOP=$s python bench.py --no-cpu-baseline --streams 1 --steps 8 --warmup 2 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):

@@ -1,7 +1,7 @@
 #!/bin/bash
 run() { # label, env...
   label=$1; shift
-  env "$@" python bench.py --no-cpu-baseline --steps 8 --warmup 2 2>/dev/null | python -c "
+  env "$@" python bench.py --no-cpu-baseline --streams 1 --steps 8 --warmup 2 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
