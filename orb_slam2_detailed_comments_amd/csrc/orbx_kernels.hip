@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void k_pyr_l0_remap(DGeom g, const uint8_t *__
 // (taps precomputed per padded coordinate on the host).  (reference :2119-2143)
 // ------------------------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(1))) orbx_uint2_u { uint32_t x, y; };   // 8 bytes at any byte address (global memory takes unaligned accesses)
+struct __attribute__((packed, aligned(1))) orbx_uint3_u { uint32_t x, y, z; };
 __device__ __forceinline__ uint2 orbx_load8(const void *p) { const orbx_uint2_u v = *(const orbx_uint2_u *)p; return make_uint2(v.x, v.y); }
 typedef unsigned short orbx_v2u16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t orbx_udot2(uint32_t a, uint32_t b) {   // a.lo * b.lo + a.hi * b.hi, exact
@@ -1178,7 +1179,7 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
         counts[f] = min(total, cap);
         if (total > cap) atomicMax(&status[f], (int)ORBX_CAPACITY);
     }
-    if (oi >= min(total, cap)) return;
+    if (oi >= min(total, cap) || dbg_stop == 4) return;
     const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];
     const int4 pat = c_pattern_lane[lane];
     uint32_t *patch = s_patch[wv_id];
@@ -1191,20 +1192,27 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
     const bool interior = px0 >= 0 && py0 >= 0 && xa + 48 <= L.pitch && x + DS_R < L.pw && y + DS_R < L.ph;
     {
         // ---- stage the 43x43 patch (rows y-21.., columns x-21..): 12 ALIGNED dwords cover the 44 bytes of a patch
-        // row; dword d of the LDS row = funnel shift of aligned dwords d, d+1 (the neighbour lane's register, one DPP
-        // move).  5 rows x 12 lanes per step, every load in flight before the first LDS write.
+        // row; dword d of the LDS row = funnel shift of aligned dwords d, d+1.  A lane loads 3 aligned dwords (one
+        // 12-byte load: a third of the load instructions of a dword per lane, the texture-address unit's rate is per
+        // lane, not per byte) and takes the 4th from the lane above (one DPP move): 4 lanes per row, 16 rows per step,
+        // every load in flight before the first LDS write.
         if (interior) {
-            const int dq = lane % 12, rq = lane / 12;
+            const int dq = lane & 3, rq = lane >> 2;
             const uint32_t shift = (uint32_t)(px0 & 3);
-            const uint8_t *p0 = img + (__mul24(py0, L.pitch) + xa + 4 * dq);   // 32-bit offsets: no 64-bit multiplies
-            uint32_t tv[9];
+            const uint8_t *p0 = img + (__mul24(py0, L.pitch) + xa + 12 * dq);   // 32-bit offsets: no 64-bit multiplies
+            orbx_uint3_u tv[3];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) tv[k] = lane < 60 ? *(const uint32_t *)(p0 + __mul24(min(5 * k + rq, DS_W - 1), L.pitch)) : 0u;
+            for (int k = 0; k < 3; ++k) tv[k] = *(const orbx_uint3_u *)(p0 + __mul24(min(16 * k + rq, DS_W - 1), L.pitch));
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const uint32_t nxt = orbx_lane_above(tv[k]);
-                const int r = 5 * k + rq;
-                if (lane < 60 && dq < 11 && r < DS_W) patch[r * (DS_PP / 4) + dq] = __builtin_amdgcn_alignbyte(nxt, tv[k], shift);
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t nxt = orbx_lane_above(tv[k].x);
+                const int r = 16 * k + rq;
+                if (r < DS_W) {
+                    uint32_t *d = patch + r * (DS_PP / 4) + 3 * dq;
+                    d[0] = __builtin_amdgcn_alignbyte(tv[k].y, tv[k].x, shift);
+                    d[1] = __builtin_amdgcn_alignbyte(tv[k].z, tv[k].y, shift);
+                    if (dq < 3) d[2] = __builtin_amdgcn_alignbyte(nxt, tv[k].z, shift);   // dword 11 of a row does not exist
+                }
             }
         } else {
             // image edge: reflect-101 of the padded level, byte by byte
