@@ -1375,77 +1375,62 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
 
 // ------------------------------------------------------------------------------------------------
 // K7: brute-force Hamming best / second-best (DescriptorDistance src/ORBmatcher.cc:2073-2093 for every
-// pair; bookkeeping of the search loops, e.g. :627-640).  One query per lane (8 dwords in VGPRs), train
-// descriptors staged through LDS in tiles and read as wave-wide broadcasts; v_xor + v_bcnt accumulate.
+// pair; bookkeeping of the search loops, e.g. :627-640).  Two queries per lane (16 dwords in VGPRs); the train
+// descriptor of an iteration is the same for the whole wave, so it is fetched with SCALAR loads (s_load_dwordx8
+// through the scalar cache) and used as the SGPR operand of v_xor: no LDS staging, no barrier, and the LDS pipe
+// (a broadcast ds_read_b128 per 8 xor/bcnt pairs was what bounded the first version) stays out of the loop.
 // ------------------------------------------------------------------------------------------------
-#define MT_SPLIT 16     // train set split over blockIdx.y (8192 waves at 64 pairs x 1000 x 1000); partials merged by k_match_merge
-#define MT_WAVES 8      // waves per block
+#define MT_SPLIT 16     // most ways the train set is split over blockIdx.y; partials merged by k_match_merge.  The launcher picks
+                        // the smallest split that still fills the chip (every extra split repeats the query loads and
+                        // one partial record per query)
+#define MT_WAVES 4      // waves per block
 #define MT_QPB (MT_WAVES * 128)   // queries per block: two per lane
-#define MT_TILE 64      // train descriptors per LDS tile (2 KB)
 __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const uint8_t *__restrict__ q, const int *__restrict__ nq,
                                                          long long q_stride, const uint8_t *__restrict__ t,
                                                          const int *__restrict__ nt, long long t_stride,
-                                                         uint2 *__restrict__ partial, int out_stride) {
-    // block = 8 waves = 1024 queries (two per lane, 16 dwords in VGPRs) against one quarter of the train set.
-    // Train descriptors are staged through LDS in 4 KB tiles (double buffered) and read back as wave-wide
-    // broadcasts, so one global read of a train descriptor feeds 1024 distance evaluations.
+                                                         uint2 *__restrict__ partial, int out_stride, int nsplit) {
     // key = dist << 20 | index: min(key) is the best match with the lowest index on ties; the second-smallest
     // key carries the second-best distance (counting duplicates), exactly the bookkeeping of the reference loops.
-    __shared__ uint4 s_t[2][MT_TILE * 2];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, pr = blockIdx.z, sp = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pr = blockIdx.z, sp = blockIdx.y;
     const int NQ = nq[pr], NT = min(nt[pr], 1 << 20);
-    if ((int)blockIdx.x * MT_QPB >= NQ) return;
-    const int qi0 = blockIdx.x * MT_QPB + w * 128 + lane, qi1 = qi0 + 64;
+    const int qw = blockIdx.x * MT_QPB + w * 128;
+    if (qw >= NQ) return;
+    const int qi0 = qw + lane, qi1 = qi0 + 64;
     const uint4 *qp = (const uint4 *)(q + (long long)pr * q_stride);
     const uint4 *tp = (const uint4 *)(t + (long long)pr * t_stride);
     uint4 qa0 = make_uint4(0, 0, 0, 0), qb0 = qa0, qa1 = qa0, qb1 = qa0;
     if (qi0 < NQ) { qa0 = qp[2 * qi0]; qb0 = qp[2 * qi0 + 1]; }
     if (qi1 < NQ) { qa1 = qp[2 * qi1]; qb1 = qp[2 * qi1 + 1]; }
-    const int chunk = (NT + MT_SPLIT - 1) / MT_SPLIT;
+    const int chunk = (NT + nsplit - 1) / nsplit;
     const int j0 = sp * chunk, j1 = min(NT, j0 + chunk);
     uint32_t best0 = 0xffffffffu, second0 = 0xffffffffu, best1 = 0xffffffffu, second1 = 0xffffffffu;
-    // first tile
-    if (tid < 2 * MT_TILE && j0 + (tid >> 1) < j1) s_t[0][tid] = tp[2 * j0 + tid];
-    __syncthreads();
-    int buf = 0;
-    for (int jt = j0; jt < j1; jt += MT_TILE) {
-        const int n = min(MT_TILE, j1 - jt);
-        const int jn = jt + MT_TILE;
-        uint4 pre = make_uint4(0, 0, 0, 0);
-        const bool do_pre = tid < 2 * MT_TILE && jn + (tid >> 1) < j1;
-        if (do_pre) pre = tp[2 * jn + tid];          // next tile in flight while this one is consumed
-        const uint4 *tile = s_t[buf];
 #pragma unroll 4
-        for (int j = 0; j < n; ++j) {
-            const uint4 ta = tile[2 * j], tb = tile[2 * j + 1];
-            const uint32_t d0 = __popc(qa0.x ^ ta.x) + __popc(qa0.y ^ ta.y) + __popc(qa0.z ^ ta.z) + __popc(qa0.w ^ ta.w) +
-                                __popc(qb0.x ^ tb.x) + __popc(qb0.y ^ tb.y) + __popc(qb0.z ^ tb.z) + __popc(qb0.w ^ tb.w);
-            const uint32_t d1 = __popc(qa1.x ^ ta.x) + __popc(qa1.y ^ ta.y) + __popc(qa1.z ^ ta.z) + __popc(qa1.w ^ ta.w) +
-                                __popc(qb1.x ^ tb.x) + __popc(qb1.y ^ tb.y) + __popc(qb1.z ^ tb.z) + __popc(qb1.w ^ tb.w);
-            const uint32_t key0 = (d0 << 20) | (uint32_t)(jt + j), key1 = (d1 << 20) | (uint32_t)(jt + j);
-            second0 = min(second0, max(best0, key0));
-            best0 = min(best0, key0);
-            second1 = min(second1, max(best1, key1));
-            best1 = min(best1, key1);
-        }
-        if (do_pre) s_t[buf ^ 1][tid] = pre;
-        __syncthreads();
-        buf ^= 1;
+    for (int j = j0; j < j1; ++j) {
+        const uint4 ta = tp[2 * j], tb = tp[2 * j + 1];   // wave-uniform address: scalar loads
+        const uint32_t d0 = __popc(qa0.x ^ ta.x) + __popc(qa0.y ^ ta.y) + __popc(qa0.z ^ ta.z) + __popc(qa0.w ^ ta.w) +
+                            __popc(qb0.x ^ tb.x) + __popc(qb0.y ^ tb.y) + __popc(qb0.z ^ tb.z) + __popc(qb0.w ^ tb.w);
+        const uint32_t d1 = __popc(qa1.x ^ ta.x) + __popc(qa1.y ^ ta.y) + __popc(qa1.z ^ ta.z) + __popc(qa1.w ^ ta.w) +
+                            __popc(qb1.x ^ tb.x) + __popc(qb1.y ^ tb.y) + __popc(qb1.z ^ tb.z) + __popc(qb1.w ^ tb.w);
+        const uint32_t key0 = (d0 << 20) | (uint32_t)j, key1 = (d1 << 20) | (uint32_t)j;
+        // best <= second always: the new second-smallest is the median of (best, second, key)  (one v_med3_u32)
+        second0 = max(min(best0, second0), min(max(best0, second0), key0));
+        best0 = min(best0, key0);
+        second1 = max(min(best1, second1), min(max(best1, second1), key1));
+        best1 = min(best1, key1);
     }
-    uint2 *po = partial + ((long long)pr * MT_SPLIT + sp) * out_stride;
+    uint2 *po = partial + ((long long)pr * nsplit + sp) * out_stride;
     if (qi0 < NQ) po[qi0] = make_uint2(best0, second0);
     if (qi1 < NQ) po[qi1] = make_uint2(best1, second1);
 }
 
 __global__ __launch_bounds__(256) void k_match_merge(const int *__restrict__ nq, const uint2 *__restrict__ partial,
                                                      int *__restrict__ best_idx, int *__restrict__ best_dist,
-                                                     int *__restrict__ second_dist, int out_stride) {
+                                                     int *__restrict__ second_dist, int out_stride, int nsplit) {
     const int pr = blockIdx.y, qi = blockIdx.x * 256 + threadIdx.x;
     if (qi >= nq[pr]) return;
     uint32_t best = 0xffffffffu, second = 0xffffffffu;
-#pragma unroll
-    for (int k = 0; k < MT_SPLIT; ++k) {
-        const uint2 p = partial[((long long)pr * MT_SPLIT + k) * out_stride + qi];
+    for (int k = 0; k < nsplit; ++k) {
+        const uint2 p = partial[((long long)pr * nsplit + k) * out_stride + qi];
         second = min(min(second, p.y), max(best, p.x));
         best = min(best, p.x);
     }
@@ -1951,10 +1936,16 @@ void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, 
                        const uint8_t *t, const int *nt, long long t_stride, int *best_idx, int *best_dist,
                        int *second_dist, int out_stride, void *workspace) {
     if (npairs <= 0 || max_nq <= 0) return;
-    hipLaunchKernelGGL(k_match, dim3((max_nq + MT_QPB - 1) / MT_QPB, MT_SPLIT, npairs), dim3(64 * MT_WAVES), 0, s, q, nq,
-                       q_stride, t, nt, t_stride, (uint2 *)workspace, out_stride);
+    // target waves per launch (a few rounds of the chip's 8192 wave slots), then the split that reaches it
+    static int target = -1;
+    if (target < 0) { const char *e = getenv("ORBX_MATCH_WAVES"); target = e ? atoi(e) : 16384; }
+    const int qblocks = (max_nq + MT_QPB - 1) / MT_QPB;
+    const long long base = (long long)qblocks * npairs * MT_WAVES;
+    const int nsplit = (int)std::min<long long>(MT_SPLIT, std::max<long long>(1, (target + base - 1) / base));
+    hipLaunchKernelGGL(k_match, dim3(qblocks, nsplit, npairs), dim3(64 * MT_WAVES), 0, s, q, nq,
+                       q_stride, t, nt, t_stride, (uint2 *)workspace, out_stride, nsplit);
     hipLaunchKernelGGL(k_match_merge, dim3((max_nq + 255) / 256, npairs), dim3(256), 0, s, nq, (const uint2 *)workspace,
-                       best_idx, best_dist, second_dist, out_stride);
+                       best_idx, best_dist, second_dist, out_stride, nsplit);
 }
 void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *dist) {
     const long long n = (long long)nq * nt;
