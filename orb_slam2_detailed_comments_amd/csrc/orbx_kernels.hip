@@ -507,19 +507,28 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     // is processed, so the global-load latency is never waited for
     const int g0 = blockIdx.y * gpw;
     const int ng = min(gpw, ngroups - g0);
-    const int rq = (lane * 49) >> 10, dq = lane - 21 * rq;   // staging: 3 rows x 21 dwords per step
-    uint32_t tv[14];
+    // staging: a lane loads 12 bytes (one load, a third of the address arithmetic and of the load instructions of a
+    // dword per lane), 7 lanes cover the 19 dwords of a tile row, 9 rows per step, 5 steps = 45 rows in registers.
+    // Row offsets are 32-bit adds from the first row's offset, clamped to the cell's last row; the address is the
+    // frame's scalar base + that 32-bit offset (global_load saddr form, no 64-bit vector arithmetic).  The lanes of a
+    // row's last 12-byte piece read past the tile into the level's next bytes (the pyramid slab has slack at its end).
+    const int rq = (lane * 37) >> 8, dq = lane - 7 * rq;   // lane / 7, lane % 7  (lane 63: rq = 9, idle)
+    orbx_uint3_u tv[5];
     OrbxFastGroup grp_n = groups[g0];
     OrbxCell c0_n = cells[grp_n.cell0], c1_n = cells[grp_n.cell0 + grp_n.ncell - 1];
+    const uint8_t *fbase = pyr + (long long)f * g.pyr_bytes;
 #define FR_PREFETCH()                                                                                                     \
     {                                                                                                                     \
         const DLevel &Ln = g.lv[c0_n.level];                                                                             \
-        const int twn = c1_n.x0 + c1_n.cw - c0_n.x0;                                                                      \
-        const int ndwn = ((c0_n.x0 & 3) + twn + 3) >> 2;                                                                  \
-        const uint8_t *srcn = pyr + (long long)f * g.pyr_bytes + Ln.off + (__mul24((int)c0_n.y0, Ln.pitch) + (c0_n.x0 & ~3) + \
-                                                                             4 * min(dq, ndwn - 1));                      \
-        _Pragma("unroll") for (int k = 0; k < 14; ++k)   /* 24-bit row offsets: 64-bit multiplies are slow */               \
-            tv[k] = *(const uint32_t *)(srcn + __mul24(min(3 * k + rq, (int)c0_n.ch - 1), Ln.pitch));                     \
+        const uint8_t *srcn = fbase + Ln.off;                                                                             \
+        uint32_t vpitch9 = (uint32_t)(9 * Ln.pitch);                                                                      \
+        asm("" : "+v"(vpitch9));   /* in a VGPR: a VOP2 add with an SGPR source issues at the slow rate */                   \
+        const uint32_t olast = (uint32_t)(__mul24((int)c0_n.y0 + (int)c0_n.ch - 1, Ln.pitch) + (c0_n.x0 & ~3) + 12 * dq); \
+        uint32_t o = (uint32_t)(__mul24((int)c0_n.y0 + min(rq, 8), Ln.pitch) + (c0_n.x0 & ~3) + 12 * dq);                \
+        _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                                   \
+            tv[k] = *(const orbx_uint3_u *)(srcn + min(o, olast));                                                        \
+            o += vpitch9;                                                                                                 \
+        }                                                                                                                 \
     }
     FR_PREFETCH()
   for (int gi = 0; gi < ng; ++gi) {
@@ -531,19 +540,30 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     const int iw0 = grp.ncell == 2 ? c0.cw - 6 : 64;
     // ---- stage the tile: prefetched registers -> LDS
     {
-        const int xa = c0.x0 & ~3, ndw = ((c0.x0 & 3) + tw + 3) >> 2;
-        const bool ld = rq < 3 && dq < ndw;
+        const int xa = c0.x0 & ~3;
+        uint32_t *trow = s_tile + rq * (FR_TP / 4) + 3 * dq;
 #pragma unroll
-        for (int k = 0; k < 14; ++k) {
-            const int r = 3 * k + rq;
-            if (ld && r < th_rows) s_tile[r * (FR_TP / 4) + dq] = tv[k];
+        for (int k = 0; k < 5; ++k) {
+            if (rq < 9 && 9 * k + rq < th_rows) {
+                uint32_t *d = trow + 9 * k * (FR_TP / 4);
+                d[0] = tv[k].x;
+                if (dq < 6) { d[1] = tv[k].y; d[2] = tv[k].z; }   // a row has 19 dwords: the 7th piece is one dword
+            }
         }
-        if (th_rows > 42) {   // cells taller than the register window (tiny pyramid levels only)
-            const uint8_t *src = pyr + (long long)f * g.pyr_bytes + L.off + (long long)c0.y0 * L.pitch + xa + 4 * min(dq, ndw - 1);
-            for (int r = 42 + rq; r < th_rows; r += 3)
-                if (ld) s_tile[r * (FR_TP / 4) + dq] = *(const uint32_t *)(src + (long long)r * L.pitch);
+        if (th_rows > 45) {   // cells taller than the register window (tiny pyramid levels only)
+            const uint8_t *src = fbase + L.off + (long long)c0.y0 * L.pitch + xa + 12 * dq;
+            for (int r = 45 + rq; r < th_rows; r += 9) {
+                if (rq < 9) {
+                    const orbx_uint3_u v = *(const orbx_uint3_u *)(src + (long long)r * L.pitch);
+                    uint32_t *d = s_tile + r * (FR_TP / 4) + 3 * dq;
+                    d[0] = v.x;
+                    if (dq < 6) { d[1] = v.y; d[2] = v.z; }
+                }
+            }
         }
-        for (int i = lane; i < th_rows * (FR_TP / 4); i += 64) ((uint32_t *)s_score)[i] = 0;
+        // score map cleared with 16-byte stores (the launcher rounds the row count to a multiple of 4, so the map is
+        // 16-byte aligned and a few bytes past the cell's last row still belong to it or to the not-yet-used list)
+        for (int i = lane; i < (th_rows * (FR_TP / 4) + 3) / 4; i += 64) ((uint4 *)s_score)[i] = make_uint4(0, 0, 0, 0);
     }
     if (gi + 1 < ng) {
         grp_n = groups[g0 + gi + 1];
@@ -672,7 +692,9 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         act = (ns0 == 0 ? 1u : 0u) | ((grp.ncell == 2 && ns1 == 0) ? 2u : 0u);
         if (act == 0) break;
         orbx_wave_sync();
-        for (int i = lane; i < th_rows * (FR_TP / 4); i += 64) ((uint32_t *)s_score)[i] = 0;
+        // score map cleared with 16-byte stores (the launcher rounds the row count to a multiple of 4, so the map is
+        // 16-byte aligned and a few bytes past the cell's last row still belong to it or to the not-yet-used list)
+        for (int i = lane; i < (th_rows * (FR_TP / 4) + 3) / 4; i += 64) ((uint4 *)s_score)[i] = make_uint4(0, 0, 0, 0);
         orbx_wave_sync();
     }
     if (lane == 0) {
@@ -1882,6 +1904,7 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
                            int ngroups, const uint8_t *pyr, uint2 *cand, int *cell_count, int max_ch, int lcap, int dbg_stop) {
     if (ngroups <= 0) return;
     lcap = (max(lcap, 64) + 1) & ~1;
+    max_ch = (max_ch + 3) & ~3;   // tile and score map sizes multiples of 16 bytes
     const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256;
     // groups per wave: FR_GPW when the launch has waves to spare (the second group's tile is prefetched while the first
     // is processed); one per wave for small batches, where the serial length of a wave is what the caller waits for
