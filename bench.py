@@ -241,7 +241,7 @@ def main():
             "kernel_ms_per_step": {k: round(v[0] / 2, 4) for k, v in prof.items()},
             "kernel_ms_overlapped": NS > 1,   # with several pipelines the per-kernel durations include time shared with other kernels
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only (the other ranks would idle through it)
             cfps, nsample = cpu_baseline(frames, NF)
             out["cpu_baseline"] = {"value": round(cfps, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": f"{nsample} frames of the same synthetic stream, single-thread CPU oracle "

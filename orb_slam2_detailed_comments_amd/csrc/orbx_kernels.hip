@@ -255,14 +255,18 @@ __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const Or
 // the source rows of step k+1 are requested before step k is evaluated, and nothing in the loop waits on a table.
 // (A variant that lays (row pair, dword) items out linearly over the lanes to remove the idle lanes of odd level widths
 // measured 258 us against 207 us: vector tap loads, rows split across a wave.)
-__global__ __launch_bounds__(256) void k_pyr_resize_rows(DGeom g, int level, const OrbxTap *__restrict__ taps,
+#ifndef RR_WPB
+#define RR_WPB 1   // waves (column strips x row ranges) per block; nothing is shared between them, and one-wave blocks
+                   // are placed as soon as any SIMD has room (201 us against 209 with 4)
+#endif
+__global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int level, const OrbxTap *__restrict__ taps,
                                                          uint8_t *__restrict__ pyr, int rpw) {
     const DLevel &L = g.lv[level];
     const DLevel &S = g.lv[level - 1];
     const int lane = threadIdx.x;
     const int X = (blockIdx.x * 64 + lane) * 4;
     const int f = blockIdx.z;
-    const int y_begin = __builtin_amdgcn_readfirstlane((blockIdx.y * 4 + threadIdx.y) * rpw);
+    const int y_begin = __builtin_amdgcn_readfirstlane((blockIdx.y * RR_WPB + threadIdx.y) * rpw);
     if (y_begin >= L.ph) return;
     const int y_end = min(y_begin + rpw, L.ph);
     const bool on = X < L.pw;
@@ -1164,6 +1168,10 @@ __constant__ uint32_t c_orient_w[64][12];
 #define DS_W (2 * DS_R + 1)     // 43
 #define DS_PP 44                // LDS patch pitch in bytes (11 dwords; rows start dword-aligned in LDS)
 #define DS_HC 40                // row-pass outputs per row (37 needed, computed in groups of 4)
+#ifndef DS_WPB
+#define DS_WPB 1   // waves (= keypoints) per block.  Nothing is shared between the waves of a block; one-wave blocks let the
+                   // dispatcher place every wave as soon as any SIMD has room: 282 us against 299 (4 waves) and 372 (8)
+#endif
 #ifndef DS_WPS
 #define DS_WPS 7   // waves per SIMD the register allocation must allow (LDS admits 7 blocks of 4 waves per CU)
 #endif
@@ -1173,21 +1181,21 @@ __constant__ uint32_t c_orient_w[64][12];
 // FPM (fp_mode) is a template constant: as a run-time value it costs a scalar branch and both code paths in each of the 8 taps
 typedef const __attribute__((address_space(3))) uint16_t *orbx_lds_u16p;
 template <int FPM>
-__global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
+__global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
                                                   const uint32_t *__restrict__ lvl_kp,
                                                   const int *__restrict__ lvl_count,
                                                   float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int *__restrict__ counts,
                                                   int *__restrict__ status, int cap, int dbg_stop) {
     // dbg_stop (ORBX_DESC_STOP, timing experiments only): 1 = after staging, 2 = after orientation, 3 = after the row pass
-    __shared__ uint32_t s_patch[4][DS_W * DS_PP / 4 + 4];
-    __shared__ __attribute__((aligned(16))) uint16_t s_h[4][DS_W * DS_HC];
+    __shared__ uint32_t s_patch[DS_WPB][DS_W * DS_PP / 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[DS_WPB][DS_W * DS_HC];
     // one wave per keypoint, waves indexed by dense OUTPUT position (level-major order of operator(), :2066-2082).
     // The wave index is wave-uniform (which the compiler cannot see): with it scalar, the level search and the position
     // load run on the scalar unit.
     const int lane = threadIdx.x & 63, wv_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int f = blockIdx.x;   // frame fastest: one frame's patches stay in one XCD's L2
-    const int oi = blockIdx.y * 4 + wv_id;
+    const int oi = blockIdx.y * DS_WPB + wv_id;
     const int *lc = lvl_count + f * g.nlevels;
     int total = 0, level = 0, slot = oi;
 #pragma unroll
@@ -1405,7 +1413,9 @@ __global__ __launch_bounds__(256, DS_WPS) void k_describe(DGeom g, const uint8_t
 #define MT_SPLIT 16     // most ways the train set is split over blockIdx.y; partials merged by k_match_merge.  The launcher picks
                         // the smallest split that still fills the chip (every extra split repeats the query loads and
                         // one partial record per query)
-#define MT_WAVES 4      // waves per block
+#ifndef MT_WAVES
+#define MT_WAVES 1      // waves per block (independent: no LDS, no barrier)
+#endif
 #define MT_QPB (MT_WAVES * 128)   // queries per block: two per lane
 __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const uint8_t *__restrict__ q, const int *__restrict__ nq,
                                                          long long q_stride, const uint8_t *__restrict__ t,
@@ -1893,8 +1903,8 @@ void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, con
         // wave are a serial chain of load -> evaluate -> store steps)
         int rpw = 16;
         while (rpw > 2 && (long long)((L.pw + 255) / 256) * ((L.ph + rpw - 1) / rpw) * B < 4096) rpw >>= 1;
-        dim3 grid((L.pw + 255) / 256, (L.ph + 4 * rpw - 1) / (4 * rpw), B);
-        hipLaunchKernelGGL(k_pyr_resize_rows, grid, dim3(64, 4), 0, s, g, level, taps, pyr, rpw);
+        dim3 grid((L.pw + 255) / 256, (L.ph + RR_WPB * rpw - 1) / (RR_WPB * rpw), B);
+        hipLaunchKernelGGL(k_pyr_resize_rows, grid, dim3(64, RR_WPB), 0, s, g, level, taps, pyr, rpw);
         return;
     }
     dim3 grid((L.pw + 255) / 256, (L.ph + 4 * RS_ROWS - 1) / (4 * RS_ROWS), B);
@@ -1948,11 +1958,11 @@ void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *p
                           int *counts, int *status, int cap) {
     static int dbg_stop = -1;
     if (dbg_stop < 0) { const char *e = getenv("ORBX_DESC_STOP"); dbg_stop = e ? atoi(e) : 0; }
-    const dim3 grid(B, (g.kp_total + 3) / 4);
+    const dim3 grid(B, (g.kp_total + DS_WPB - 1) / DS_WPB);
     if (g.fp_mode == ORBX_FP_GCC_FMA)
-        hipLaunchKernelGGL(k_describe<ORBX_FP_GCC_FMA>, grid, dim3(256), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
+        hipLaunchKernelGGL(k_describe<ORBX_FP_GCC_FMA>, grid, dim3(64 * DS_WPB), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
     else
-        hipLaunchKernelGGL(k_describe<ORBX_FP_STRICT>, grid, dim3(256), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
+        hipLaunchKernelGGL(k_describe<ORBX_FP_STRICT>, grid, dim3(64 * DS_WPB), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
 }
 size_t orbx_match_workspace_bytes(int npairs, int out_stride) { return (size_t)npairs * MT_SPLIT * out_stride * sizeof(uint2); }
 void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,
