@@ -55,6 +55,31 @@ __device__ __forceinline__ int orbx_reflect101(int i, int n) {
 __device__ __forceinline__ uint32_t orbx_lane_above(uint32_t v) {   // value of lane + 1 (lane 63 gets 0)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ORBX_DPP_WAVE_SHL1, 0xf, 0xf, true);
 }
+// inclusive prefix sum over the 64 lanes (the canonical GCN DPP scan: shift-adds inside each row of 16, then the row
+// broadcasts): 8 DPP adds against 6 ds_bpermute round trips for a __shfl_up ladder
+__device__ __forceinline__ int orbx_wave_scan(int v) {
+    int t = v + __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_SHR(1), 0xf, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_SHR(2), 0xf, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_SHR(3), 0xf, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, t, ORBX_DPP_ROW_SHR(4), 0xf, 0xe, true);
+    t += __builtin_amdgcn_update_dpp(0, t, ORBX_DPP_ROW_SHR(8), 0xf, 0xc, true);
+    t += __builtin_amdgcn_update_dpp(0, t, ORBX_DPP_ROW_BCAST15, 0xa, 0xf, true);
+    t += __builtin_amdgcn_update_dpp(0, t, ORBX_DPP_ROW_BCAST31, 0xc, 0xf, true);
+    return t;
+}
+// minimum over the 64 lanes, returned wave-uniform (same ladder; lanes without a source keep the identity)
+__device__ __forceinline__ uint32_t orbx_wave_min(uint32_t v) {
+    const int I = -1;
+    const int iv = (int)v;
+    uint32_t t = min(v, (uint32_t)__builtin_amdgcn_update_dpp(I, iv, ORBX_DPP_ROW_SHR(1), 0xf, 0xf, false));
+    t = min(t, (uint32_t)__builtin_amdgcn_update_dpp(I, iv, ORBX_DPP_ROW_SHR(2), 0xf, 0xf, false));
+    t = min(t, (uint32_t)__builtin_amdgcn_update_dpp(I, iv, ORBX_DPP_ROW_SHR(3), 0xf, 0xf, false));
+    t = min(t, (uint32_t)__builtin_amdgcn_update_dpp(I, (int)t, ORBX_DPP_ROW_SHR(4), 0xf, 0xe, false));
+    t = min(t, (uint32_t)__builtin_amdgcn_update_dpp(I, (int)t, ORBX_DPP_ROW_SHR(8), 0xf, 0xc, false));
+    t = min(t, (uint32_t)__builtin_amdgcn_update_dpp(I, (int)t, ORBX_DPP_ROW_BCAST15, 0xa, 0xf, false));
+    t = min(t, (uint32_t)__builtin_amdgcn_update_dpp(I, (int)t, ORBX_DPP_ROW_BCAST31, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)t, 63);
+}
 // sum over the 64 lanes, returned wave-uniform: shift-adds inside each row of 16, then row broadcasts (the canonical
 // GCN reduction), result read from lane 63
 __device__ __forceinline__ int orbx_wave_sum(int v) {

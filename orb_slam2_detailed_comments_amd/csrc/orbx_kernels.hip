@@ -742,12 +742,7 @@ __device__ uint32_t qt_block_scan(const uint32_t *in, uint32_t *out, int n, QtSh
     for (int base = 0; base < n; base += QT_THREADS) {
         const int i = base + tid;
         const uint32_t v = i < n ? in[i] : 0;
-        uint32_t incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
+        const uint32_t incl = (uint32_t)orbx_wave_scan((int)v);
         if (lane == 63) sh->wsum[w] = incl;
         __syncthreads();
         uint32_t off = carry, tot = 0;
@@ -1548,8 +1543,7 @@ __device__ __forceinline__ void orbx_stereo_body(const OrbxStereoGeom &sg, const
             if (d < 100u) best = min(best, (d << 16) | (uint32_t)iR);   // bestDist starts at TH_HIGH, strict '<'
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 64));
+    best = orbx_wave_min(best);
     if (best == 0xffffffffu || (best >> 16) >= 75u) return;  // thOrbDist = (TH_HIGH + TH_LOW) / 2
     const int bestIdxR = (int)(best & 0xffffu);
     const float uR0 = kR[bestIdxR].x;
