@@ -148,6 +148,7 @@ def main():
             msecond=torch.zeros((B, cap), dtype=torch.int32, device=dev),
             done=torch.cuda.Event()))
     gatherer = sharding.RecordGatherer(B, cap, dev, mode=args.gather) if world > 1 else None
+    torch.cuda.synchronize(dev)   # the zero fills above ran on torch's default stream; the pipelines' streams are not ordered with it
     state = {"i": 0}
 
     def step():

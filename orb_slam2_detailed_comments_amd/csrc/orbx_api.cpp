@@ -220,6 +220,10 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     HIPCHK(hipMemset(h->d_pyr, 0, (size_t)B * g.pyr_bytes));
     HIPCHK(hipMemset(h->d_lvl_count, 0, (size_t)B * NL * sizeof(int)));
     HIPCHK(hipMemset(h->d_cand_count, 0, (size_t)B * NL * sizeof(int)));
+    // hipMemset of device memory is asynchronous on the NULL stream, and the handle's streams are non-blocking (not
+    // ordered with it): without this barrier a delayed memset can land on top of the first batch's pyramid (seen once,
+    // as a zeroed level 0 read-back, with five processes sharing the GPU)
+    HIPCHK(hipDeviceSynchronize());
     h->configured = true;
     h->last_batch = 0;
     return ORBX_OK;
@@ -337,6 +341,7 @@ extern "C" orbx_status orbx_set_rectification(orbx_handle *h, const float *map_x
     }
     HIPCHK(hipMalloc(&h->d_rect, t.size() * sizeof(uint2)));
     HIPCHK(hipMemcpy(h->d_rect, t.data(), t.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIPCHK(hipDeviceSynchronize());   // NULL-stream copy vs the handle's non-blocking stream
     h->rect_w = width; h->rect_h = height;
     return ORBX_OK;
 }
@@ -573,6 +578,7 @@ extern "C" orbx_status orbx_debug_blur_copy(orbx_handle *h, int frame, int level
         if (!h->d_blur) {      // the blurred slab only exists for inspection: allocated on first request
             HIPCHK(hipMalloc(&h->d_blur, (size_t)h->p.max_batch * h->geom.pyr_bytes + 256));
             HIPCHK(hipMemset(h->d_blur, 0, (size_t)h->p.max_batch * h->geom.pyr_bytes));
+            HIPCHK(hipDeviceSynchronize());   // NULL-stream memset vs the handle's non-blocking stream
         }
         { ProfScope ps(h, ORBX_K_BLUR);
           orbx_launch_blur(h->stream, h->dg, h->last_batch, h->d_pyr, h->d_blur); }
@@ -1252,6 +1258,7 @@ extern "C" orbx_status orbx_vocabulary_create(orbx_handle *h, const orbx_vocabul
     if (e == hipSuccess) e = hipMemcpy(v->d_child_begin, view->child_begin, (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess && nchild > 0) e = hipMemcpy(v->d_child_ids, view->child_ids, (size_t)nchild * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(v->d_desc, view->desc, (size_t)n * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // NULL-stream copies vs the handles' non-blocking streams
     if (e != hipSuccess) { orbx_vocabulary_destroy(v); return fail(ORBX_HIP_ERROR, hipGetErrorString(e)); }
     *out = v;
     return ORBX_OK;

@@ -156,6 +156,7 @@ def test_compute_stereo_matches_batched_device_path():
         bufs[name] = d
     ur = torch.zeros((B, cap), dtype=torch.float32, device=dev); dep = torch.zeros_like(ur)
     nm = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()   # fills ran on torch's stream; the handles' streams are not ordered with it
     L = _capi.lib()
     _capi.check(L.orbx_stereo_match_batch_device(exL.handle, exR.handle, B, _capi.ptr(bufs["L"]["kps"]), _capi.ptr(bufs["L"]["desc"]),
                                                  _capi.ptr(bufs["L"]["cnt"]), _capi.ptr(bufs["R"]["kps"]), _capi.ptr(bufs["R"]["desc"]),

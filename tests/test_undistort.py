@@ -69,6 +69,7 @@ def test_gpu_undistort_equals_oracle():
     cnt = torch.zeros(B, dtype=torch.int32, device=dev); st = torch.zeros(B, dtype=torch.int32, device=dev)
     ex.extract_batch_device(torch.from_numpy(frames).to(dev), B, 640, 480, 640, 640 * 480, kps, desc, cnt, st, cap)
     un = torch.zeros_like(kps)
+    torch.cuda.synchronize()   # fills ran on torch's stream; the handle's stream is not ordered with it
     k4 = np.array(TUM1["K"], np.float32); dd = np.array(TUM1["D"], np.float32)
     _capi.check(_capi.lib().orbx_undistort_keypoints_device(ex.handle, B, _capi.ptr(kps), _capi.ptr(cnt), cap, _capi.ptr(k4), _capi.ptr(dd), 5, _capi.ptr(un)))
     ex.synchronize()

@@ -26,6 +26,7 @@ kps = torch.zeros((B, cap * 28), dtype=torch.uint8, device=dev); dsc = torch.zer
 cnt = torch.zeros(B, dtype=torch.int32, device=dev); st = torch.zeros(B, dtype=torch.int32, device=dev)
 ex.extract_batch_device(d_imgs, B, 640, 480, 640, 640 * 480, kps, dsc, cnt, st, cap)
 leaf = torch.zeros((B, cap), dtype=torch.int32, device=dev); nid = torch.zeros_like(leaf)
+torch.cuda.synchronize()
 L_ = _capi.lib()
 def run():
     _capi.check(L_.orbx_bow_transform_device(ex.handle, V._h, B, _capi.ptr(dsc), _capi.ptr(cnt), cap * 32, cap, 4, _capi.ptr(leaf),

@@ -13,6 +13,7 @@ cap = ex.max_keypoints(640, 480)
 d_kps = torch.zeros((B + 1, cap * 28), dtype=torch.uint8, device=dev); d_desc = torch.zeros((B + 1, cap * 32), dtype=torch.uint8, device=dev)
 d_cnt = torch.zeros(B + 1, dtype=torch.int32, device=dev); d_st = torch.zeros(B, dtype=torch.int32, device=dev)
 mi = torch.zeros((B, cap), dtype=torch.int32, device=dev); mb = torch.zeros_like(mi); ms = torch.zeros_like(mi)
+torch.cuda.synchronize()
 L = _capi.lib()
 for i in range(4):
     ex.extract_batch_device(d_imgs, B, 640, 480, 640, 640 * 480, d_kps[1:], d_desc[1:], d_cnt[1:], d_st, cap)

@@ -40,4 +40,5 @@ while time.time() - t0 < budget:
             oc, gc = orc.level_candidates(l), ex.debug_candidates(l, cap=1 << 21)
             assert sorted(zip(oc["x"], oc["y"], oc["response"])) == sorted(zip(gc["x"], gc["y"], gc["response"])), f"candidates level {l}: {tag}"
     n += 1; nkp += on
+    if n % 200 == 0: print(f"  .. {n} configurations, {nkp} keypoints, {time.time() - t0:.0f} s", flush=True)
 print(f"soak ok: {n} random configurations ({skipped} unsupported geometries skipped), {nkp} keypoints compared bit for bit in {time.time() - t0:.0f} s")

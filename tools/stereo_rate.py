@@ -18,6 +18,7 @@ for name, w, h, nf, B, mb, mbf in (("KITTI 1241x376/2000", 1241, 376, 2000, 64, 
                  desc=torch.zeros((B, cap * 32), dtype=torch.uint8, device=dev), cnt=torch.zeros(B, dtype=torch.int32, device=dev),
                  st=torch.zeros(B, dtype=torch.int32, device=dev)) for k in "LR"}
     ur = torch.zeros((B, cap), dtype=torch.float32, device=dev); dep = torch.zeros_like(ur); nm = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
     stream = torch.cuda.Stream(device=dev)
     for k in "LR": ex[k].set_stream(stream.cuda_stream)
     def step():
