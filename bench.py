@@ -4,9 +4,11 @@
 A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
   K0..K6 extraction of `--batch` frames (per GPU) + K7 brute-force Hamming match of frame t vs t-1
   (+ for N > 1 one RCCL gather of the per-frame keypoint records).
-Consecutive steps run on `--streams` pipelines (one handle + HIP stream each) round-robin, so the tail of step i overlaps the
-head of step i+1; every step still does all of its work, and frame 0 of a step is matched against the last frame of the
-step before it (an event links the pipelines).
+By default the steps run one after the other on one pipeline (handle + HIP stream), so that the per-kernel durations behind
+`roofline` (HIP events on the launch stream) are the kernels' own and agree with rocprofv3 of the same command.
+`--streams N` runs consecutive steps on N pipelines round-robin (the tail of step i overlaps the head of step i+1; every step
+still does all of its work, frame 0 of a step is matched against the last frame of the step before it through an event):
++8 % frames/s at N = 3, but a kernel's duration then includes the time it shares the chip with its neighbours' kernels.
 Weak scaling: every rank owns its own batch; no collective on the data path.
 """
 import argparse
@@ -95,10 +97,10 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=1,
                     help="extract+match pipelines per GPU (handle + HIP stream each), used round-robin over the steps: the "
                          "latency-bound tail of one step (quadtree, small pyramid levels) overlaps the issue-bound kernels of "
-                         "the next (+12 %% at 3).  --streams 1 gives un-overlapped per-kernel durations (DESIGN.md section 6 table)")
+                         "the next (+8 %% frames/s at 3, DESIGN.md section 6).  The default 1 keeps per-kernel durations un-overlapped")
     ap.add_argument("--gather", default="gather", choices=("gather", "all_gather"),
                     help="collective for the per-frame keypoint records: to rank 0 (default) or to every rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
