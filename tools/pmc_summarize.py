@@ -6,7 +6,9 @@ files = glob.glob(path + '/**/*counter_collection.csv', recursive=True)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in files:
     for r in csv.DictReader(open(fn)):
-        agg[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+        name = r['Kernel_Name'].split('(')[0]
+        if name.startswith('void '): name = name[5:]      # template instances: "void k_describe<0>(...)"
+        agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in sorted(agg.items()):
     if not k.startswith('k_'):
         continue
