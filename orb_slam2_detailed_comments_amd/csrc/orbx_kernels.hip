@@ -726,7 +726,9 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
 //   * the address tie-break of std::sort over pair<int,ExtractorNode*> is defined as creation order (F3).
 // Selection (:1387-1413) = max response, first in emission order, via one 64-bit LDS atomicMax per key.
 // ------------------------------------------------------------------------------------------------
+#ifndef QT_THREADS
 #define QT_THREADS 512
+#endif
 
 struct QtShared {
     int size, prev_size, n_expand, ctot, nmtot, jstar, m, finish;
