@@ -821,13 +821,24 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
     const int nc = L.cell_count;
     const int chunk = (nc + QT_THREADS - 1) / QT_THREADS;
     const int c_begin = min(tid * chunk, nc), c_end = min(c_begin + chunk, nc);
+    // The first cell of a thread (the only one at the usual one cell per thread) keeps its record, count and first four
+    // slots in registers across the scan: the slot loads are issued BEFORE the scan, so the chain is
+    // {count, cell record} -> slots (under the scan) -> stores instead of count -> scan -> cell record -> slots -> stores.
+    OrbxCell cl0 = {};
+    int cnt0 = 0;
+    uint2 p0 = make_uint2(0, 0), p1 = p0, p2 = p0, p3 = p0;
     {
         uint32_t mine = 0;
         for (int i = c_begin; i < c_end; ++i) {
+            const OrbxCell cl = cells[L.cell_begin + i];
             int c = cell_count[(long long)f * g.ncells + L.cell_begin + i];
-            const int cap = cells[L.cell_begin + i].slot_cap;
-            if (c > cap) { atomicMax(&status[f], (int)ORBX_CAPACITY); c = cap; }
+            if (c > cl.slot_cap) { atomicMax(&status[f], (int)ORBX_CAPACITY); c = cl.slot_cap; }
             mine += (uint32_t)c;
+            if (i == c_begin) {
+                cl0 = cl; cnt0 = c;
+                const uint2 *src = slots + cl.slot_begin;   // (slot ranges are always mapped)
+                p0 = src[0]; p1 = src[min(1, cl.slot_cap - 1)]; p2 = src[min(2, cl.slot_cap - 1)]; p3 = src[min(3, cl.slot_cap - 1)];
+            }
         }
         cscan[tid] = mine;
     }
@@ -837,12 +848,15 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
     {
         uint32_t o = cscan[tid];
         for (int i = c_begin; i < c_end; ++i) {
-            const OrbxCell cl = cells[L.cell_begin + i];
-            const int c = min(cell_count[(long long)f * g.ncells + L.cell_begin + i], cl.slot_cap);
+            OrbxCell cl; int c; uint2 e0, e1, e2, e3;
+            if (i == c_begin) { cl = cl0; c = cnt0; e0 = p0; e1 = p1; e2 = p2; e3 = p3; }
+            else {
+                cl = cells[L.cell_begin + i];
+                c = min(cell_count[(long long)f * g.ncells + L.cell_begin + i], cl.slot_cap);
+                const uint2 *srcn = slots + cl.slot_begin;
+                e0 = srcn[0]; e1 = srcn[min(1, cl.slot_cap - 1)]; e2 = srcn[min(2, cl.slot_cap - 1)]; e3 = srcn[min(3, cl.slot_cap - 1)];
+            }
             const uint2 *src = slots + cl.slot_begin;
-            // the first four entries are fetched together (slot ranges are always mapped): one memory round trip
-            // covers the typical cell, which holds 0..4 survivors
-            const uint2 e0 = src[0], e1 = src[min(1, cl.slot_cap - 1)], e2 = src[min(2, cl.slot_cap - 1)], e3 = src[min(3, cl.slot_cap - 1)];
             for (int e = 0; e < c; ++e) {
                 const uint2 v = e == 0 ? e0 : e == 1 ? e1 : e == 2 ? e2 : e == 3 ? e3 : src[e];
                 cand[o + e] = v;
