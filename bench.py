@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of ORB extract + match on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
-  K0..K6 extraction of `--batch` frames (per GPU) + K7 brute-force Hamming match of frame t vs t-1
+A step = one pass of the hot path over one batch of synthetic frames already resident in HBM.
+  mono configs  : K0..K6 extraction of `--batch` frames (per GPU) + K7 brute-force Hamming match of frame t vs t-1
+  stereo configs: K0..K6 extraction of both eyes of `--batch` stereo pairs (two extractor handles, as src/Frame.cc:158-168
+                  uses two extractor objects) + Frame::ComputeStereoMatches with its median cut, all on the device
   (+ for N > 1 one RCCL gather of the per-frame keypoint records).
+`--config` selects the BASELINE.json configuration (default: the headline one, config 2):
+  tum           synthetic 640x480 mono stream, nFeatures 1000      (configs 1/2, Examples/Monocular/TUM1.yaml:30-43)
+  kitti_stereo  synthetic 1241x376 stereo pairs, nFeatures 2000    (config 3, Examples/Stereo/KITTI00-02.yaml:18-51)
+  euroc_stereo  synthetic 752x480 stereo pairs, nFeatures 1200     (config 4, Examples/Stereo/EuRoC.yaml:18-106)
+  hd1080        synthetic 1920x1080 mono stream, nFeatures 4000    (config 5)
 By default the steps run one after the other on one pipeline (handle + HIP stream), so that the per-kernel durations behind
 `roofline` (HIP events on the launch stream) are the kernels' own and agree with rocprofv3 of the same command.
-`--streams N` runs consecutive steps on N pipelines round-robin (the tail of step i overlaps the head of step i+1; every step
-still does all of its work, frame 0 of a step is matched against the last frame of the step before it through an event):
-+8 % frames/s at N = 3, but a kernel's duration then includes the time it shares the chip with its neighbours' kernels.
-Weak scaling: every rank owns its own batch; no collective on the data path.
+`--streams N` (mono) runs consecutive steps on N pipelines round-robin; a kernel's duration then includes the time it shares the
+chip with its neighbours' kernels.  Weak scaling: every rank owns its own batch; no collective on the data path.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,7 +33,17 @@ import torch.distributed as dist
 from orb_slam2_detailed_comments_amd import ORBextractor, synth, _capi
 from orb_slam2_detailed_comments_amd import sharding
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SCLK_PEAK_HZ = 2.4e9    # same guide: max clock 2400 MHz
+N_SIMD = 1024           # 256 CUs x 4 SIMD-32
+PROFILE_TAG = "r02"     # profiles/<tag>_traffic.json, profiles/<tag>_sq.json
+
+CONFIGS = {   # name: (width, height, nfeatures, frames or pairs per GPU per step, stereo, mb, mbf)
+    "tum": (640, 480, 1000, 256, False, 0.0, 0.0),
+    "kitti_stereo": (1241, 376, 2000, 64, True, 0.537, 386.1448),     # bf 386.1448, fx 718.856 (KITTI00-02.yaml)
+    "euroc_stereo": (752, 480, 1200, 128, True, 0.11, 47.90639384423901),   # EuRoC.yaml: Camera.bf
+    "hd1080": (1920, 1080, 4000, 32, False, 0.0, 0.0),
+}
 
 
 def level_pixels(ex, w, h):
@@ -40,52 +56,81 @@ def level_pixels(ex, w, h):
     return out
 
 
-def algorithmic_bytes(ex, w, h, n_kp):
-    """per-frame algorithmic bytes of each kernel (SURVEY.md section 8d model, split per kernel)"""
+def algorithmic_bytes(ex, w, h, n_kp, stereo):
+    """Per-image algorithmic bytes of each kernel.  "model" = SURVEY.md section 8(d), which was written for an
+    unfused pipeline (GaussianBlur reads and writes the whole pyramid: 2P); "fused" = what the kernels here must move
+    (the Gaussian is evaluated inside k_describe on a 43x43 patch per keypoint, the blurred image is never written)."""
     P = level_pixels(ex, w, h)
     Pt = sum(P)
-    return {
+    model = {
         "k_pyr_l0": w * h + P[0],
         "k_pyr_resize": (Pt - P[-1]) + (Pt - P[0]),
         "k_fast_rows": Pt,
         "k_quadtree": 0,
         "k_orient": n_kp * 749,
-        "k_blur": 0,                                   # fused into k_describe (the blurred image is never written)
-        "k_describe": 2 * Pt + n_kp * 512 + n_kp * 60,  # SURVEY 8d: blur read+write + descriptor taps + output
+        "k_blur": 0,
+        "k_describe": 2 * Pt + n_kp * 512 + n_kp * 60,   # 8(d): blur read + write, descriptor taps, output
         "k_match": 2 * n_kp * 32 + n_kp * 12,
     }
+    fused = dict(model)
+    fused["k_orient"] = 0                                   # the orientation disc lies inside the descriptor's patch
+    fused["k_describe"] = n_kp * (43 * 43) + n_kp * 60      # one un-blurred 43x43 patch per keypoint + keypoint / descriptor out
+    if stereo:   # ComputeStereoMatches: both descriptor sets + keypoints once, two 11x21 SAD windows per matched keypoint
+        model["k_match"] = fused["k_match"] = 2 * n_kp * (32 + 28) // 2 + n_kp * (11 * 11 + 11 * 21) // 2 + n_kp * 8 // 2
+    return model, fused
 
 
-def measured_traffic(kernel, B, W, H, NF):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
-    separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 calibration in tools/fetch_calib.hip).
-    None when the committed counters were taken on another workload."""
+def kernels_hash():
+    """identity of the device code the committed PMC counters were taken on"""
+    h = hashlib.sha256()
+    for f in ("orbx_kernels.hip", "orbx_device.h"):
+        h.update(open(os.path.join(ROOT, "orb_slam2_detailed_comments_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(kind, cfg_name, B, W, H, NF):
+    """profiles/<tag>_{traffic,sq}.json (separate rocprofv3 --pmc passes, tools/make_traffic_json.py / tools/make_sq_json.py).
+    Returns None unless the file was taken on THIS workload with THIS device code (kernel source hash): a stale file reads
+    as 'not measured', never as a number."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if (t["batch"], t["width"], t["height"], t["nfeatures"]) != (B, W, H, NF):
+        t = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{kind}.json")))
+        if t.get("kernels_sha256_16") != kernels_hash():
             return None
-        return int(t["kernels"][kernel]["hbm_bytes_per_launch"])
+        if (t["batch"], t["width"], t["height"], t["nfeatures"]) != (B, W, H, NF) or t.get("config", "tum") != cfg_name:
+            return None
+        return t
     except Exception:
         return None
 
 
-def cpu_baseline(frames, nfeatures, budget_s=20.0):
-    """single-thread CPU oracle (port of the reference path) on a bounded sample of the same frames"""
+def cpu_baseline(frames, right, nfeatures, stereo, mb, mbf, budget_s=20.0):
+    """single-thread CPU oracle (port of the reference path) on a bounded sample of the same frames, pinned to one core"""
     import oracle
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[-1]})   # SURVEY 8(d): taskset -c <core>
+        pinned = True
+    except Exception:
+        pinned = False
     orc = oracle.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
+    orcR = oracle.OracleExtractor(nfeatures, 1.2, 8, 20, 7) if stereo else None
+    tabs = orc.tables()
     t0 = time.perf_counter()
     n = 0
     prev = None
-    for f in frames:
+    for i, f in enumerate(frames):
         _, k, d = orc.extract(f)
-        if prev is not None:
+        if stereo:
+            _, kr, dr = orcR.extract(right[i])
+            pl = [orc.level_image(l) for l in range(8)]; pr = [orcR.level_image(l) for l in range(8)]
+            oracle.stereo_matches(k, d, kr, dr, tabs["scale"], tabs["inv_scale"], pl, pr, mb, mbf)
+        elif prev is not None:
             oracle.match_bruteforce(d, prev)
         prev = d
         n += 1
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return n / dt, n
+    return n / dt, n, pinned
 
 
 def main():
@@ -93,14 +138,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--config", default="tum", choices=sorted(CONFIGS), help="BASELINE.json configuration (default: the headline one)")
+    ap.add_argument("--batch", type=int, default=0, help="frames (stereo: pairs) per GPU per step; 0 = the config's default")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--nfeatures", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1,
-                    help="extract+match pipelines per GPU (handle + HIP stream each), used round-robin over the steps: the "
-                         "latency-bound tail of one step (quadtree, small pyramid levels) overlaps the issue-bound kernels of "
-                         "the next (+8 %% frames/s at 3, DESIGN.md section 6).  The default 1 keeps per-kernel durations un-overlapped")
+                    help="extract+match pipelines per GPU (handle + HIP stream each), used round-robin over the steps (mono "
+                         "configs).  The default 1 keeps per-kernel durations un-overlapped")
     ap.add_argument("--gather", default="gather", choices=("gather", "all_gather"),
                     help="collective for the per-frame keypoint records: to rank 0 (default) or to every rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -124,31 +169,50 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    B, W, H, NF = args.batch, args.width, args.height, args.nfeatures
-    NS = max(1, args.streams)
-    frames = synth.stream(W, H, B, stream_id=100 + rank)
-    d_imgs = torch.from_numpy(frames).to(dev)
+    cW, cH, cNF, cB, stereo, mb, mbf = CONFIGS[args.config]
+    B, W, H, NF = args.batch or cB, args.width or cW, args.height or cH, args.nfeatures or cNF
+    NS = 1 if stereo else max(1, args.streams)
     L = _capi.lib()
+    right = None
+    if stereo:   # 8 distinct synthetic pairs (right = left scene re-rendered with per-rectangle disparity), repeated to fill the batch
+        base = [synth.stereo_pair(W, H, stream_id=70 + 8 * rank + i) for i in range(8)]
+        frames = np.stack([base[i % 8][0] for i in range(B)]); right = np.stack([base[i % 8][1] for i in range(B)])
+    else:
+        frames = synth.stream(W, H, B, stream_id=100 + rank)
+    d_imgs = torch.from_numpy(frames).to(dev)
+    d_right = torch.from_numpy(right).to(dev) if stereo else None
     # NS independent pipelines (handle + HIP stream + result buffers), used round-robin: while one batch is in its
     # latency-bound tail (quadtree, small pyramid levels) the next batch's streaming kernels fill the chip.
     exs = [ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B, device=local_rank) for _ in range(NS)]
+    exR = ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B, device=local_rank) if stereo else None
     ex = exs[0]
     cap = ex.max_keypoints(W, H)
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     for e, st in zip(exs, streams):
         e.set_stream(st.cuda_stream)
+    if stereo:
+        exR.set_stream(streams[0].cuda_stream)
     # slot 0 of the result buffers carries the last frame of the previous step (match t vs t-1)
     bufs = []
     for _ in range(NS):
-        bufs.append(dict(
+        b = dict(
             kps=torch.zeros((B + 1, cap * 28), dtype=torch.uint8, device=dev),
             desc=torch.zeros((B + 1, cap * 32), dtype=torch.uint8, device=dev),
             counts=torch.zeros(B + 1, dtype=torch.int32, device=dev),
             status=torch.zeros(B, dtype=torch.int32, device=dev),
             midx=torch.zeros((B, cap), dtype=torch.int32, device=dev),
             mbest=torch.zeros((B, cap), dtype=torch.int32, device=dev),
-            msecond=torch.zeros((B, cap), dtype=torch.int32, device=dev),
-            done=torch.cuda.Event()))
+            msecond=torch.zeros((B, cap), dtype=torch.int32, device=dev))
+        if stereo:
+            b.update(kpsR=torch.zeros((B, cap * 28), dtype=torch.uint8, device=dev),
+                     descR=torch.zeros((B, cap * 32), dtype=torch.uint8, device=dev),
+                     countsR=torch.zeros(B, dtype=torch.int32, device=dev), statusR=torch.zeros(B, dtype=torch.int32, device=dev),
+                     uright=torch.zeros((B, cap), dtype=torch.float32, device=dev), depth=torch.zeros((B, cap), dtype=torch.float32, device=dev),
+                     nmatch=torch.zeros(B, dtype=torch.int32, device=dev))
+        bufs.append(b)
+    # descriptors + count of the last frame of the previous step (the train set of pair 0), handed from step to step
+    carry = dict(desc=torch.zeros(cap * 32, dtype=torch.uint8, device=dev), count=torch.zeros(1, dtype=torch.int32, device=dev),
+                 ready=torch.cuda.Event())
     gatherer = sharding.RecordGatherer(B, cap, dev, mode=args.gather) if world > 1 else None
     torch.cuda.synchronize(dev)   # the zero fills above ran on torch's default stream; the pipelines' streams are not ordered with it
     state = {"i": 0}
@@ -157,42 +221,50 @@ def main():
         i = state["i"]; state["i"] = i + 1
         k = i % NS
         e, st, b = exs[k], streams[k], bufs[k]
-        prev = bufs[(i - 1) % NS]
         with torch.cuda.stream(st):
             e.extract_batch_device(d_imgs, B, W, H, W, W * H, b["kps"][1:], b["desc"][1:], b["counts"][1:], b["status"], cap)
-            if i > 0:
-                st.wait_event(prev["done"])        # the previous batch's last frame is the train set of pair 0
-            b["desc"][0].copy_(prev["desc"][B]); b["counts"][0:1].copy_(prev["counts"][B:B + 1])
-            _capi.check(L.orbx_match_bruteforce_device(
-                e.handle, B, _capi.ptr(b["desc"][1:]), _capi.ptr(b["counts"][1:]), cap * 32, _capi.ptr(b["desc"]),
-                _capi.ptr(b["counts"]), cap * 32, _capi.ptr(b["midx"]), _capi.ptr(b["mbest"]), _capi.ptr(b["msecond"]), cap))
+            if stereo:
+                exR.extract_batch_device(d_right, B, W, H, W, W * H, b["kpsR"], b["descR"], b["countsR"], b["statusR"], cap)
+                _capi.check(L.orbx_stereo_match_batch_device(
+                    e.handle, exR.handle, B, _capi.ptr(b["kps"][1:]), _capi.ptr(b["desc"][1:]), _capi.ptr(b["counts"][1:]),
+                    _capi.ptr(b["kpsR"]), _capi.ptr(b["descR"]), _capi.ptr(b["countsR"]), cap, mb, mbf,
+                    _capi.ptr(b["uright"]), _capi.ptr(b["depth"]), _capi.ptr(b["nmatch"])))
+            else:
+                if i > 0:
+                    st.wait_event(carry["ready"])   # written at the end of step i-1 (possibly on another pipeline's stream)
+                b["desc"][0].copy_(carry["desc"]); b["counts"][0:1].copy_(carry["count"])
+                _capi.check(L.orbx_match_bruteforce_device(
+                    e.handle, B, _capi.ptr(b["desc"][1:]), _capi.ptr(b["counts"][1:]), cap * 32, _capi.ptr(b["desc"]),
+                    _capi.ptr(b["counts"]), cap * 32, _capi.ptr(b["midx"]), _capi.ptr(b["mbest"]), _capi.ptr(b["msecond"]), cap))
+                carry["desc"].copy_(b["desc"][B]); carry["count"].copy_(b["counts"][B:B + 1])
+                carry["ready"].record(st)
             if gatherer is not None:
                 gatherer.gather(b["counts"][1:], b["kps"][1:], b["desc"][1:], async_op=True)
-            b["done"].record(st)
 
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize(dev)
-    status = torch.stack([b["status"] for b in bufs]).cpu().numpy()
+    status = torch.stack([b["status"] for b in bufs] + ([bufs[0]["statusR"]] if stereo else [])).cpu().numpy()
     if status.any():
         raise SystemExit(f"extraction reported status {status.tolist()}")
     counts = bufs[0]["counts"][1:].cpu().numpy()
     n_kp = float(counts.mean())
+    handles = exs + ([exR] if stereo else [])
 
     # calibration pass: which kernel dominates?  (all kernels timed with HIP events on the launch stream)
-    for e in exs:
+    for e in handles:
         e.profile_enable(0x1ff)
     for _ in range(2 * NS):
         step()
     prof = {}
-    for e in exs:
+    for e in handles:
         for kname, (ms, n) in e.profile_read(reset=True).items():
             a = prof.get(kname, (0.0, 0))
             prof[kname] = (a[0] + ms, a[1] + n)
     prof = {kname: (v[0] / NS, v[1] // NS) for kname, v in prof.items()}   # per 2 steps, like the single-pipeline table
     dominant = max((k for k in prof if k != "misc"), key=lambda k: prof[k][0])
     kid = _capi.K_NAMES.index(dominant)
-    for e in exs:
+    for e in handles:
         e.profile_enable(1 << kid)
 
     if world > 1:
@@ -212,43 +284,67 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     dom_ms, dom_launches = 0.0, 0
-    for e in exs:
+    for e in handles:
         ms_, n_ = e.profile_read(reset=True)[dominant]
         dom_ms += ms_; dom_launches += n_
         e.profile_enable(0)
 
     if rank == 0:
-        fps = world * B * args.steps / dt
-        ab = algorithmic_bytes(ex, W, H, n_kp)
+        fps = world * B * args.steps / dt                      # mono: frames/s; stereo: stereo frames (left + right image)/s
+        imgs_per_unit = 2 if stereo else 1
+        model, fused = algorithmic_bytes(ex, W, H, n_kp, stereo)
         launches_per_step = dom_launches / max(args.steps, 1)
-        bytes_per_launch = ab[dominant] * B / max(launches_per_step, 1e-9)
+        # bytes one launch of the dominant kernel processes (both eyes' launches counted as launches)
+        bytes_per_launch = model[dominant] * B * imgs_per_unit / max(launches_per_step, 1e-9)
         avg_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        total_ab = sum(ab.values())
+        total_model = sum(model.values()) * imgs_per_unit
+        total_fused = sum(fused.values()) * imgs_per_unit
+        traffic = committed_counters("traffic", args.config, B, W, H, NF)
+        sq = committed_counters("sq", args.config, B, W, H, NF)
+        issue_frac = None
+        if sq is not None and dominant in sq["kernels"] and avg_launch_s > 0:
+            # wave-instructions of the three in-order issue classes over the slots a SIMD offers at the full VALU cadence
+            # (one wave64 instruction per 2 cycles per SIMD-32, at the 2.4 GHz peak clock, over the LIVE launch duration)
+            ks = sq["kernels"][dominant]
+            insts = ks["SQ_INSTS_VALU"] + ks["SQ_INSTS_SALU"] + ks["SQ_INSTS_LDS"]
+            issue_frac = round(insts / (avg_launch_s * SCLK_PEAK_HZ / 2 * N_SIMD), 4)
+        metric = {"tum": "frames/sec ORB extract+match (1000 kp, 640x480)"}.get(
+            args.config if (W, H, NF) == (640, 480, 1000) else "", f"frames/sec ORB extract+match ({NF} kp, {W}x{H}{', stereo' if stereo else ''})")
+        kind = (f"synthetic {W}x{H} stereo stream (stereo frame = left + right image, both extracted), nFeatures={NF}, 8 levels, "
+                f"scale 1.2, FAST 20/7, extract x2 + ComputeStereoMatches, batch {B} stereo frames/GPU resident in HBM"
+                if stereo else
+                f"synthetic {W}x{H} mono stream, nFeatures={NF}, 8 levels, scale 1.2, FAST 20/7, "
+                f"extract+match(t vs t-1), batch {B} frames/GPU resident in HBM, {NS} pipelines/GPU")
         out = {
-            "metric": "frames/sec ORB extract+match (1000 kp, 640x480)",
+            "metric": metric,
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"synthetic {W}x{H} mono stream, nFeatures={NF}, 8 levels, scale 1.2, FAST 20/7, "
-                                   f"extract+match(t vs t-1), batch {B} frames/GPU resident in HBM, {NS} pipelines/GPU",
-                       "frames_per_gpu_per_step": B, "mean_keypoints": round(n_kp, 1),
+            "config": {"workload": kind, "name": args.config, "frames_per_gpu_per_step": B, "mean_keypoints": round(n_kp, 1),
+                       "images_per_s": round(fps * imgs_per_unit, 1),
                        "parallelism": f"frames sharded x{world}, RCCL {args.gather} of keypoint records per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(dominant, B, W, H, NF),
+                         "traffic": int(traffic["kernels"][dominant]["hbm_bytes_per_launch"]) if traffic and dominant in traffic["kernels"] else None,
+                         "issue_frac": issue_frac,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_us": round(avg_launch_s * 1e6, 2),
-                         "end_to_end_GBs": round(total_ab * fps / world / 1e9, 2),
-                         "end_to_end_frac": round(total_ab * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
+                         # SURVEY 8(d) model (unfused pipeline: includes 2P for a blurred image that is never written here) ...
+                         "end_to_end_GBs": round(total_model * fps / world / 1e9, 2),
+                         "end_to_end_frac": round(total_model * fps / world / 1e9 / HBM_PEAK_GBS, 5),
+                         # ... and the bytes the fused kernels really have to move
+                         "end_to_end_fused_GBs": round(total_fused * fps / world / 1e9, 2),
+                         "end_to_end_fused_frac": round(total_fused * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_step": {k: round(v[0] / 2, 4) for k, v in prof.items()},
             "kernel_ms_overlapped": NS > 1,   # with several pipelines the per-kernel durations include time shared with other kernels
         }
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only (the other ranks would idle through it)
-            cfps, nsample = cpu_baseline(frames, NF)
+            cfps, nsample, pinned = cpu_baseline(frames, right, NF, stereo, mb, mbf)
             out["cpu_baseline"] = {"value": round(cfps, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": f"{nsample} frames of the same synthetic stream, single-thread CPU oracle "
-                                             f"(extract + brute-force match), host has {os.cpu_count()} cores"}
+                                   "sample": f"{nsample} {'stereo frames' if stereo else 'frames'} of the same synthetic stream, "
+                                             f"single-thread CPU oracle (extract{' x2 + ComputeStereoMatches' if stereo else ' + brute-force match'}), "
+                                             f"{'pinned to one core' if pinned else 'not pinned'}, host has {os.cpu_count()} cores"}
         if args.stages:
             for k, v in prof.items():
                 print(f"  {k:14s} {v[0] / 2:9.4f} ms/step  ({v[1] // 2} launches/step)", file=sys.stderr)

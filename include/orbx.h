@@ -128,7 +128,9 @@ orbx_status orbx_pyramid_level_copy(orbx_handle *h, int frame, int level, uint8_
  *      (query, train) pair with the best / second-best bookkeeping of the search loops
  *      (e.g. src/ORBmatcher.cc:627-640).  Device pointers, asynchronous on the handle's stream.
  *      npairs independent problems: pair p uses query rows d_q + p*q_stride (nq[p] rows) and train
- *      rows d_t + p*t_stride (nt[p] rows); outputs [npairs][out_stride]. ---------------------------- */
+ *      rows d_t + p*t_stride (nt[p] rows); outputs [npairs][out_stride].  Contract: out_stride is the
+ *      query capacity -- queries beyond it are ignored (nq[p] is clamped to out_stride on the device,
+ *      nothing is written outside row p of the outputs). --------------------------------------------- */
 orbx_status orbx_match_bruteforce_device(orbx_handle *h, int npairs, const uint8_t *d_q,
                                          const int32_t *d_nq, int64_t q_stride, const uint8_t *d_t,
                                          const int32_t *d_nt, int64_t t_stride, int32_t *d_best_idx,

@@ -41,7 +41,7 @@ struct orbx_handle {
     OrbxCell *d_cells = nullptr;
     OrbxFastGroup *d_groups = nullptr;
     bool resize_legacy = false;   // ORBX_RESIZE_IMPL=legacy: k_pyr_resize for every level (A/B runs)
-    int fast_stop = 0;      // ORBX_FAST_STOP: timing experiments only
+    int fast_stop = 0;      // ORBX_FAST_STOP: only read in -DORBX_TIMING_KNOBS builds
     int fast_lcap = 640;    // LDS work-list entries of k_fast_rows (ORBX_FAST_LCAP; tests shrink it to force the flush paths)
     OrbxTap *d_taps = nullptr;
     uint2 *d_cand = nullptr, *d_dense = nullptr;   // per-cell candidate slots / dense per-level key arrays
@@ -188,42 +188,72 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     d.blur_tiles = tiles;
     // quadtree LDS plan: node tables always in LDS, key->node map in LDS when the level's candidates fit
     h->ncap = g.node_cap;
-    // keys of a level (position + node index) live in LDS when they fit 4096 slots (24 KB): keeps >= 2 workgroups per CU;
-    // denser levels fall back to the global scratch map (same code path through a generic pointer)
+    // Keys of a level (position + node index, 6 bytes each) live in LDS when they fit `lds_keys` slots; denser levels fall
+    // back to the global scratch map (same code path through a generic pointer).  The kernel is latency-bound (a chain of
+    // barrier-separated stages), so what counts is how many workgroups a CU holds: take the largest residency (4 = the wave
+    // limit of 512-thread workgroups, then 3, 2, 1) whose key slots still cover ~6 candidates per kept keypoint of the
+    // densest level (level 0 of the 640x480 bench frames has 1230 candidates for 217 keypoints), capped at 4096.
     const size_t node_part = orbx_quadtree_smem(h->ncap, 0);
     if (node_part > 120 * 1024) return fail(ORBX_UNSUPPORTED, "nfeatures too large for the LDS quadtree node table");
-    h->lds_keys = (int)std::min<size_t>(4096, (size_t)g.max_cand_cap);   // 6 bytes per key: position + node
-    HIPCHK(orbx_quadtree_prepare(orbx_quadtree_smem(h->ncap, h->lds_keys)));
-    // buffers
-    HIPCHK(hipMalloc(&h->d_pyr, (size_t)B * g.pyr_bytes + 256));   // +256: kernels read whole aligned dwords
-    HIPCHK(hipMalloc(&h->d_cells, std::max<size_t>(1, g.cells.size()) * sizeof(OrbxCell)));
-    HIPCHK(hipMalloc(&h->d_taps, std::max<size_t>(1, g.taps.size()) * sizeof(OrbxTap)));
-    HIPCHK(hipMalloc(&h->d_cand, (size_t)B * g.cand_total * sizeof(uint2)));
-    HIPCHK(hipMalloc(&h->d_dense, (size_t)B * g.cand_total * sizeof(uint2)));
-    HIPCHK(hipMalloc(&h->d_cell_count, (size_t)B * std::max<size_t>(1, g.cells.size()) * sizeof(int)));
-    HIPCHK(hipMalloc(&h->d_knode, (size_t)B * g.cand_total * sizeof(uint16_t)));
-    HIPCHK(hipMalloc(&h->d_cand_count, (size_t)B * NL * sizeof(int)));
-    HIPCHK(hipMalloc(&h->d_lvl_count, (size_t)B * NL * sizeof(int)));
-    HIPCHK(hipMalloc(&h->d_status, (size_t)B * sizeof(int)));
-    HIPCHK(hipMalloc(&h->d_lvl_kp, (size_t)B * g.kp_total * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&h->d_lvl_angle, (size_t)B * g.kp_total * sizeof(float)));
-    HIPCHK(hipMalloc(&h->d_groups, std::max<size_t>(1, g.fast_groups.size()) * sizeof(OrbxFastGroup)));
-    if (!g.cells.empty()) {
-        HIPCHK(hipMemcpy(h->d_cells, g.cells.data(), g.cells.size() * sizeof(OrbxCell), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->d_groups, g.fast_groups.data(), g.fast_groups.size() * sizeof(OrbxFastGroup), hipMemcpyHostToDevice));
+    {
+        const size_t want = std::min<size_t>({(size_t)4096, (size_t)g.max_cand_cap, (size_t)6 * (size_t)std::max(g.lv[0].nfeat, 1)});
+        size_t keys = 0;
+        for (int wg = 4; wg >= 1 && keys == 0; --wg) {
+            const size_t budget = (size_t)(160 * 1024) / wg - 512;   // allocation granularity margin
+            if (budget <= node_part) continue;
+            const size_t fit = std::min<size_t>({(budget - node_part) / 6, (size_t)4096, (size_t)g.max_cand_cap});
+            if (fit >= want || wg == 1) keys = fit;
+        }
+        if (const char *e = getenv("ORBX_QT_LDS_KEYS")) keys = std::min<size_t>((size_t)std::max(atoi(e), 0), std::min<size_t>(8192, (160 * 1024 - node_part) / 6));
+        h->lds_keys = (int)keys;
     }
+    HIPCHK(orbx_quadtree_prepare(orbx_quadtree_smem(h->ncap, h->lds_keys)));
+    // buffers.  Every fill / upload below is issued on the handle's stream: the kernels that read them are launched on
+    // the same stream, so the order holds by construction (hipMemset on the NULL stream is asynchronous and NOT ordered
+    // with a non-blocking stream -- the round-1 race -- and a device-wide barrier would stall every other handle).
+    // Source vectors live in h->geom (they outlive the copies).
     if (const char *e = getenv("ORBX_RESIZE_IMPL")) h->resize_legacy = strcmp(e, "legacy") == 0;
+#ifdef ORBX_TIMING_KNOBS   // phase-timing builds only (tools/build_variant.sh): stops k_fast_rows early, results are wrong
     if (const char *e = getenv("ORBX_FAST_STOP")) h->fast_stop = atoi(e);
+#endif
     if (const char *e = getenv("ORBX_FAST_LCAP")) h->fast_lcap = std::max(64, atoi(e));
-    if (!g.taps.empty())
-        HIPCHK(hipMemcpy(h->d_taps, g.taps.data(), g.taps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(h->d_pyr, 0, (size_t)B * g.pyr_bytes));
-    HIPCHK(hipMemset(h->d_lvl_count, 0, (size_t)B * NL * sizeof(int)));
-    HIPCHK(hipMemset(h->d_cand_count, 0, (size_t)B * NL * sizeof(int)));
-    // hipMemset of device memory is asynchronous on the NULL stream, and the handle's streams are non-blocking (not
-    // ordered with it): without this barrier a delayed memset can land on top of the first batch's pyramid (seen once,
-    // as a zeroed level 0 read-back, with five processes sharing the GPU)
-    HIPCHK(hipDeviceSynchronize());
+    const OrbxGeom &hg = h->geom;
+    hipStream_t s = h->stream;
+    auto setup = [&]() -> hipError_t {
+        hipError_t e;
+#define ORBX_TRY(expr) do { e = (expr); if (e != hipSuccess) return e; } while (0)
+        ORBX_TRY(hipMalloc(&h->d_pyr, (size_t)B * hg.pyr_bytes + 256));   // +256: kernels read whole aligned dwords
+        ORBX_TRY(hipMalloc(&h->d_cells, std::max<size_t>(1, hg.cells.size()) * sizeof(OrbxCell)));
+        ORBX_TRY(hipMalloc(&h->d_taps, std::max<size_t>(1, hg.taps.size()) * sizeof(OrbxTap)));
+        ORBX_TRY(hipMalloc(&h->d_cand, (size_t)B * hg.cand_total * sizeof(uint2)));
+        ORBX_TRY(hipMalloc(&h->d_dense, (size_t)B * hg.cand_total * sizeof(uint2)));
+        ORBX_TRY(hipMalloc(&h->d_cell_count, (size_t)B * std::max<size_t>(1, hg.cells.size()) * sizeof(int)));
+        ORBX_TRY(hipMalloc(&h->d_knode, (size_t)B * hg.cand_total * sizeof(uint16_t)));
+        ORBX_TRY(hipMalloc(&h->d_cand_count, (size_t)B * NL * sizeof(int)));
+        ORBX_TRY(hipMalloc(&h->d_lvl_count, (size_t)B * NL * sizeof(int)));
+        ORBX_TRY(hipMalloc(&h->d_status, (size_t)B * sizeof(int)));
+        ORBX_TRY(hipMalloc(&h->d_lvl_kp, (size_t)B * hg.kp_total * sizeof(uint32_t)));
+        ORBX_TRY(hipMalloc(&h->d_lvl_angle, (size_t)B * hg.kp_total * sizeof(float)));
+        ORBX_TRY(hipMalloc(&h->d_groups, std::max<size_t>(1, hg.fast_groups.size()) * sizeof(OrbxFastGroup)));
+        if (!hg.cells.empty()) {
+            ORBX_TRY(hipMemcpyAsync(h->d_cells, hg.cells.data(), hg.cells.size() * sizeof(OrbxCell), hipMemcpyHostToDevice, s));
+            ORBX_TRY(hipMemcpyAsync(h->d_groups, hg.fast_groups.data(), hg.fast_groups.size() * sizeof(OrbxFastGroup),
+                                    hipMemcpyHostToDevice, s));
+        }
+        if (!hg.taps.empty())
+            ORBX_TRY(hipMemcpyAsync(h->d_taps, hg.taps.data(), hg.taps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice, s));
+        ORBX_TRY(hipMemsetAsync(h->d_pyr, 0, (size_t)B * hg.pyr_bytes + 256, s));
+        ORBX_TRY(hipMemsetAsync(h->d_lvl_count, 0, (size_t)B * NL * sizeof(int), s));
+        ORBX_TRY(hipMemsetAsync(h->d_cand_count, 0, (size_t)B * NL * sizeof(int), s));
+#undef ORBX_TRY
+        return hipSuccess;
+    };
+    const hipError_t se = setup();
+    if (se != hipSuccess) {   // nothing half-allocated survives a failed configure()
+        hipStreamSynchronize(s);
+        free_geometry_buffers(h);
+        return fail(ORBX_HIP_ERROR, std::string("configure: ") + hipGetErrorString(se));
+    }
     h->configured = true;
     h->last_batch = 0;
     return ORBX_OK;
@@ -340,8 +370,9 @@ extern "C" orbx_status orbx_set_rectification(orbx_handle *h, const float *map_x
         t[i].y = (uint32_t)(((sy & 31) << 5) | (sx & 31));
     }
     HIPCHK(hipMalloc(&h->d_rect, t.size() * sizeof(uint2)));
-    HIPCHK(hipMemcpy(h->d_rect, t.data(), t.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    HIPCHK(hipDeviceSynchronize());   // NULL-stream copy vs the handle's non-blocking stream
+    // on the handle's stream (ordered with the kernels that read the maps); `t` is a local: wait for the copy, on this stream only
+    HIPCHK(hipMemcpyAsync(h->d_rect, t.data(), t.size() * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     h->rect_w = width; h->rect_h = height;
     return ORBX_OK;
 }
@@ -577,8 +608,7 @@ extern "C" orbx_status orbx_debug_blur_copy(orbx_handle *h, int frame, int level
         HIPCHK(hipSetDevice(h->dev));
         if (!h->d_blur) {      // the blurred slab only exists for inspection: allocated on first request
             HIPCHK(hipMalloc(&h->d_blur, (size_t)h->p.max_batch * h->geom.pyr_bytes + 256));
-            HIPCHK(hipMemset(h->d_blur, 0, (size_t)h->p.max_batch * h->geom.pyr_bytes));
-            HIPCHK(hipDeviceSynchronize());   // NULL-stream memset vs the handle's non-blocking stream
+            HIPCHK(hipMemsetAsync(h->d_blur, 0, (size_t)h->p.max_batch * h->geom.pyr_bytes, h->stream));   // ordered with k_blur below
         }
         { ProfScope ps(h, ORBX_K_BLUR);
           orbx_launch_blur(h->stream, h->dg, h->last_batch, h->d_pyr, h->d_blur); }
@@ -1255,10 +1285,12 @@ extern "C" orbx_status orbx_vocabulary_create(orbx_handle *h, const orbx_vocabul
     hipError_t e = hipMalloc(&v->d_child_begin, (size_t)(n + 1) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&v->d_child_ids, std::max<size_t>(1, nchild) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&v->d_desc, (size_t)n * 32);
-    if (e == hipSuccess) e = hipMemcpy(v->d_child_begin, view->child_begin, (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess && nchild > 0) e = hipMemcpy(v->d_child_ids, view->child_ids, (size_t)nchild * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(v->d_desc, view->desc, (size_t)n * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipDeviceSynchronize();   // NULL-stream copies vs the handles' non-blocking streams
+    // the vocabulary is shared by every handle of the device: upload on the creating handle's stream and wait for THAT stream
+    // (the tables are complete before any other stream can be handed the object; no device-wide barrier)
+    if (e == hipSuccess) e = hipMemcpyAsync(v->d_child_begin, view->child_begin, (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && nchild > 0) e = hipMemcpyAsync(v->d_child_ids, view->child_ids, (size_t)nchild * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(v->d_desc, view->desc, (size_t)n * 32, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { orbx_vocabulary_destroy(v); return fail(ORBX_HIP_ERROR, hipGetErrorString(e)); }
     *out = v;
     return ORBX_OK;

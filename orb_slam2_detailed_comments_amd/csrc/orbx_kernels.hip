@@ -14,6 +14,18 @@
 // one thread -> 4 horizontally adjacent padded pixels (one dword store)
 // ------------------------------------------------------------------------------------------------
 #define L0_ROWS 8   // rows per thread: 8 independent row loads in flight per lane (the kernel is pure streaming)
+// Grid order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so with the FRAME as the fastest grid
+// dimension (batch % 8 == 0) every block of one frame lands on the same XCD and the source lines two neighbouring blocks
+// both touch (strip seams, reflected rows, the border block's byte gathers) are fetched from HBM once instead of once per XCD.
+#ifndef L0_FF
+#define L0_FF 1
+#endif
+#ifndef RR_FF
+#define RR_FF 1
+#endif
+#ifndef QT_FF
+#define QT_FF 1
+#endif
 __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restrict__ imgs, int W, int H, int stride,
                                                 long long frame_stride, uint8_t *__restrict__ pyr, int xe) {
     // block = 64 x 4 threads, thread = L0_ROWS rows.  Blocks with blockIdx.x < gridDim.x - 1 copy the interior
@@ -21,13 +33,17 @@ __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restri
     // owns the two border strips [0, 32) and [xe, pitch) where reflect-101 reverses the byte order (byte gathers).
     // Keeping the two roles in different blocks keeps every wave free of divergence.
     const DLevel &L = g.lv[0];
-    const int Y0 = (blockIdx.y * 4 + threadIdx.y) * L0_ROWS;
-    const int f = blockIdx.z;
+#if L0_FF
+    const int f = blockIdx.x, bx = blockIdx.y, by = blockIdx.z, nbx = gridDim.y;
+#else
+    const int f = blockIdx.z, bx = blockIdx.x, by = blockIdx.y, nbx = gridDim.x;
+#endif
+    const int Y0 = (by * 4 + threadIdx.y) * L0_ROWS;
     if (Y0 >= L.ph) return;
     const uint8_t *img = imgs + (long long)f * frame_stride;
     uint8_t *dst = pyr + (long long)f * g.pyr_bytes + L.off;
-    if (blockIdx.x + 1 < gridDim.x) {
-        const int X = 32 + (blockIdx.x * 64 + threadIdx.x) * 16;
+    if (bx + 1 < nbx) {
+        const int X = 32 + (bx * 64 + threadIdx.x) * 16;
         if (X >= xe) return;
         uint4 v[L0_ROWS];
 #pragma unroll
@@ -264,9 +280,13 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
     const DLevel &L = g.lv[level];
     const DLevel &S = g.lv[level - 1];
     const int lane = threadIdx.x;
-    const int X = (blockIdx.x * 64 + lane) * 4;
-    const int f = blockIdx.z;
-    const int y_begin = __builtin_amdgcn_readfirstlane((blockIdx.y * RR_WPB + threadIdx.y) * rpw);
+#if RR_FF
+    const int f = blockIdx.x, bx = blockIdx.y, by = blockIdx.z;
+#else
+    const int f = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+#endif
+    const int X = (bx * 64 + lane) * 4;
+    const int y_begin = __builtin_amdgcn_readfirstlane((by * RR_WPB + threadIdx.y) * rpw);
     if (y_begin >= L.ph) return;
     const int y_end = min(y_begin + rpw, L.ph);
     const bool on = X < L.pw;
@@ -359,9 +379,25 @@ __device__ __forceinline__ void orbx_wave_sync() {
 //     LDS footprint is independent of how many pixels pass;
 //   * NMS walks the corner list when every corner of the group fitted it, otherwise it rescans the score map.
 // ------------------------------------------------------------------------------------------------
+#ifndef FR_GLDS
+#define FR_GLDS 1       // 1: the tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass);
+                        // 0: the round-1 staging (12-byte register loads of the NEXT tile, written to LDS one group later)
+#endif
 #ifndef FR_TP
+#if FR_GLDS
+#define FR_TP 80        // LDS tile pitch = 5 x 16 bytes: one LDS-DMA instruction (64 lanes x 16 B, lane-linear) covers 12.8 rows
+#else
 #define FR_TP 76        // LDS tile pitch: 64 interior columns + 6 ring + 3 alignment bytes -> 19 dwords (odd: rows spread over all banks)
 #endif
+#endif
+// bytes of the LDS tile region for `rows` tile rows: whole LDS-DMA instructions (1 KiB each) in the FR_GLDS layout
+__host__ __device__ static inline int fr_tile_bytes(int rows) {
+#if FR_GLDS
+    return ((rows * (FR_TP / 16) + 63) / 64) * 1024;
+#else
+    return rows * FR_TP;
+#endif
+}
 #ifndef FR_WPS
 #define FR_WPS 4
 #endif
@@ -498,12 +534,15 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
                                                           const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
                                                           int *__restrict__ cell_count, int rows, int lcap, int ngroups,
                                                           int gpw, int dbg_stop) {
-    // dbg_stop (ORBX_FAST_STOP, timing experiments only; results are wrong unless 0): 1 = after staging, 2 = after the
-    // pre-test, 3 = after the ring test, 4 = before NMS
+    // dbg_stop (ORBX_FAST_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS; results are wrong unless 0): 1 = after
+    // staging, 2 = after the pre-test, 3 = after the ring test, 4 = before NMS.  The shipped library pins it to 0.
+#ifndef ORBX_TIMING_KNOBS
+    dbg_stop = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
     uint32_t *s_tile = (uint32_t *)fast_smem;
-    uint8_t *s_score = fast_smem + rows * FR_TP;
-    uint16_t *s_list = (uint16_t *)(fast_smem + 2 * rows * FR_TP);   // lcap entries + one private dummy dword per lane
+    uint8_t *s_score = fast_smem + fr_tile_bytes(rows);
+    uint16_t *s_list = (uint16_t *)(s_score + rows * FR_TP);   // lcap entries + one private dummy dword per lane
     uint16_t *s_corn = s_list + lcap + 128;
     const int lane = threadIdx.x;
     const int f = blockIdx.x;   // frame fastest: all groups of one frame share one XCD's L2
@@ -511,6 +550,23 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     // is processed, so the global-load latency is never waited for
     const int g0 = blockIdx.y * gpw;
     const int ng = min(gpw, ngroups - g0);
+#if FR_GLDS
+    // staging by LDS-DMA: chunk c = 64 k + lane of instruction k is 16 bytes, tile row c / 5, byte column 16 (c % 5); the
+    // LDS image is lane-linear (M0 base + 16 lane), which IS the row-major tile at pitch 80.  Per tile and instruction the
+    // lane's source offset is min(row, last row) * pitch + column + the tile origin: two vector instructions, and the data
+    // never passes through VGPRs (round 1 staged 5 twelve-byte loads per lane through registers and ~15 ds_write_b32).
+    OrbxFastGroup grp_n = groups[g0];
+    OrbxCell c0_n = cells[grp_n.cell0], c1_n = cells[grp_n.cell0 + grp_n.ncell - 1];
+    const uint8_t *fbase = pyr + (long long)f * g.pyr_bytes;
+    uint32_t ck_row[4], ck_col[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t c = 64u * k + (uint32_t)lane;
+        ck_row[k] = (c * 13108u) >> 16;          // c / 5 for c < 16384
+        ck_col[k] = 16u * (c - 5u * ck_row[k]);
+    }
+    const uint32_t lds_tile = (uint32_t)(uintptr_t)(fr_lds_u16 *)s_tile;   // LDS byte address of the tile (wave-uniform)
+#else
     // staging: a lane loads 12 bytes (one load, a third of the address arithmetic and of the load instructions of a
     // dword per lane), 7 lanes cover the 19 dwords of a tile row, 9 rows per step, 5 steps = 45 rows in registers.
     // Row offsets are 32-bit adds from the first row's offset, clamped to the cell's last row; the address is the
@@ -535,6 +591,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         }                                                                                                                 \
     }
     FR_PREFETCH()
+#endif
   for (int gi = 0; gi < ng; ++gi) {
     const OrbxFastGroup grp = grp_n;
     const OrbxCell c0 = c0_n, c1 = c1_n;
@@ -542,6 +599,38 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     const int tw = c1.x0 + c1.cw - c0.x0, th_rows = c0.ch;
     const int niw = tw - 6;                                   // interior columns of the group (<= 64)
     const int iw0 = grp.ncell == 2 ? c0.cw - 6 : 64;
+#if FR_GLDS
+    // ---- stage the tile: LDS-DMA straight from the pyramid level (the previous group's tile reads have all returned: their
+    // results were consumed), score map cleared while the loads are in flight, then wait for them
+    {
+        const uint8_t *src = fbase + L.off + (long long)__mul24((int)c0.y0, L.pitch) + (c0.x0 & ~3);   // wave-uniform
+        const uint32_t last = (uint32_t)(th_rows - 1);
+        const int ninstr = (th_rows * (FR_TP / 16) + 63) >> 6;
+        for (int k = 0; k < ninstr; ++k) {
+            uint32_t row, col;
+            if (k < 4) { row = k == 0 ? ck_row[0] : k == 1 ? ck_row[1] : k == 2 ? ck_row[2] : ck_row[3];
+                         col = k == 0 ? ck_col[0] : k == 1 ? ck_col[1] : k == 2 ? ck_col[2] : ck_col[3]; }
+            else { const uint32_t c = 64u * k + (uint32_t)lane; row = (c * 13108u) >> 16; col = 16u * (c - 5u * row); }
+            const uint32_t off = __umul24(min(row, last), (uint32_t)L.pitch) + col;
+            uint32_t keep;
+            // M0 = LDS destination of this instruction; saved / restored inside the statement (the compiler owns M0)
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %3\n\t"
+                         "s_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %2\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(off), "s"(src), "s"(lds_tile + 1024u * (uint32_t)k)
+                         : "memory");
+        }
+        for (int i = lane; i < (th_rows * (FR_TP / 4) + 3) / 4; i += 64) ((uint4 *)s_score)[i] = make_uint4(0, 0, 0, 0);
+        if (gi + 1 < ng) {
+            grp_n = groups[g0 + gi + 1];
+            c0_n = cells[grp_n.cell0]; c1_n = cells[grp_n.cell0 + grp_n.ncell - 1];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA writes are counted in vmcnt (the compiler does not see them)
+    }
+#else
     // ---- stage the tile: prefetched registers -> LDS
     {
         const int xa = c0.x0 & ~3;
@@ -574,6 +663,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         c0_n = cells[grp_n.cell0]; c1_n = cells[grp_n.cell0 + grp_n.ncell - 1];
         FR_PREFETCH()
     }
+#endif
     FrCtx cx;
     cx.tile = (const uint8_t *)s_tile + (c0.x0 & 3);
     cx.score = s_score;
@@ -785,7 +875,13 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
                                                         int *__restrict__ status, uint16_t *__restrict__ knode_glob,
                                                         int ncap, int lds_keys) {
     extern __shared__ __attribute__((aligned(16))) uint8_t qt_smem[];
+    // grid: frame fastest, level 0 (the most keys) dispatched first.  With the level fastest, workgroup id % 8 = level for
+    // the usual 8 levels: one XCD would get every level-0 workgroup and another every level-7 one.
+#if QT_FF
+    const int level = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
+#else
     const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+#endif
     const DLevel &L = g.lv[level];
     const int N = L.nfeat;
     const uint2 *slots = slots_all + (long long)f * g.cand_total + L.cand_begin;
@@ -1198,7 +1294,11 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
                                                   float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int *__restrict__ counts,
                                                   int *__restrict__ status, int cap, int dbg_stop) {
-    // dbg_stop (ORBX_DESC_STOP, timing experiments only): 1 = after staging, 2 = after orientation, 3 = after the row pass
+    // dbg_stop (ORBX_DESC_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS): 1 = after staging, 2 = after orientation,
+    // 3 = after the row pass.  The shipped library pins it to 0.
+#ifndef ORBX_TIMING_KNOBS
+    dbg_stop = 0;
+#endif
     __shared__ uint32_t s_patch[DS_WPB][DS_W * DS_PP / 4 + 4];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[DS_WPB][DS_W * DS_HC];
     // one wave per keypoint, waves indexed by dense OUTPUT position (level-major order of operator(), :2066-2082).
@@ -1435,7 +1535,7 @@ __global__ __launch_bounds__(64 * MT_WAVES) void k_match(const uint8_t *__restri
     // key = dist << 20 | index: min(key) is the best match with the lowest index on ties; the second-smallest
     // key carries the second-best distance (counting duplicates), exactly the bookkeeping of the reference loops.
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pr = blockIdx.z, sp = blockIdx.y;
-    const int NQ = nq[pr], NT = min(nt[pr], 1 << 20);
+    const int NQ = min(nq[pr], out_stride), NT = min(nt[pr], 1 << 20);   // contract (orbx.h): counts beyond out_stride are ignored
     const int qw = blockIdx.x * MT_QPB + w * 128;
     if (qw >= NQ) return;
     const int qi0 = qw + lane, qi1 = qi0 + 64;
@@ -1470,7 +1570,7 @@ __global__ __launch_bounds__(256) void k_match_merge(const int *__restrict__ nq,
                                                      int *__restrict__ best_idx, int *__restrict__ best_dist,
                                                      int *__restrict__ second_dist, int out_stride, int nsplit) {
     const int pr = blockIdx.y, qi = blockIdx.x * 256 + threadIdx.x;
-    if (qi >= nq[pr]) return;
+    if (qi >= min(nq[pr], out_stride)) return;
     uint32_t best = 0xffffffffu, second = 0xffffffffu;
     for (int k = 0; k < nsplit; ++k) {
         const uint2 p = partial[((long long)pr * nsplit + k) * out_stride + qi];
@@ -1845,6 +1945,7 @@ __global__ void k_clear(int *a, int na, int *b, int nb, int *c, int nc) {
 #include "orbx_launch.h"
 #include <string>
 #include <cstdio>
+#include <mutex>
 
 hipError_t orbx_upload_pattern() {
     signed char t[64 * 16];
@@ -1891,7 +1992,11 @@ void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *img
     int xe = 32;
     while (xe + 1 <= W) xe += 16;           // chunk at X reads source bytes [X - 22, X + 1): must end inside the row
     const int icols = (xe - 32 + 1023) / 1024;
+#if L0_FF
+    dim3 grid(B, icols + 1, (L.ph + 4 * L0_ROWS - 1) / (4 * L0_ROWS));
+#else
     dim3 grid(icols + 1, (L.ph + 4 * L0_ROWS - 1) / (4 * L0_ROWS), B);
+#endif
     hipLaunchKernelGGL(k_pyr_l0, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, xe);
 }
 void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
@@ -1913,7 +2018,11 @@ void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, con
         // wave are a serial chain of load -> evaluate -> store steps)
         int rpw = 16;
         while (rpw > 2 && (long long)((L.pw + 255) / 256) * ((L.ph + rpw - 1) / rpw) * B < 4096) rpw >>= 1;
+#if RR_FF
+        dim3 grid(B, (L.pw + 255) / 256, (L.ph + RR_WPB * rpw - 1) / (RR_WPB * rpw));
+#else
         dim3 grid((L.pw + 255) / 256, (L.ph + RR_WPB * rpw - 1) / (RR_WPB * rpw), B);
+#endif
         hipLaunchKernelGGL(k_pyr_resize_rows, grid, dim3(64, RR_WPB), 0, s, g, level, taps, pyr, rpw);
         return;
     }
@@ -1925,7 +2034,7 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
     if (ngroups <= 0) return;
     lcap = (max(lcap, 64) + 1) & ~1;
     max_ch = (max_ch + 3) & ~3;   // tile and score map sizes multiples of 16 bytes
-    const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256;
+    const size_t smem = (size_t)fr_tile_bytes(max_ch) + (size_t)max_ch * FR_TP + (size_t)4 * lcap + 256;
     // groups per wave: FR_GPW when the launch has waves to spare (the second group's tile is prefetched while the first
     // is processed); one per wave for small batches, where the serial length of a wave is what the caller waits for
     const int gpw = (long long)B * ngroups >= 16384 ? FR_GPW : 1;
@@ -1954,11 +2063,22 @@ void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *
                           const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,
                           int *status, uint16_t *knode_glob, int ncap, int lds_keys) {
     const size_t smem = orbx_quadtree_smem(ncap, lds_keys);
-    hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, B), dim3(QT_THREADS), smem, s, g, cells, slots, cell_count, dense,
+    hipLaunchKernelGGL(k_quadtree, QT_FF ? dim3(B, g.nlevels) : dim3(g.nlevels, B), dim3(QT_THREADS), smem, s, g, cells, slots, cell_count, dense,
                        cand_count, lvl_kp, lvl_count, status, knode_glob, ncap, lds_keys);
 }
 hipError_t orbx_quadtree_prepare(size_t smem) {
-    return hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    // The attribute belongs to (function, device), not to a handle: ORB-SLAM2 itself keeps mpIniORBextractor (2 x nFeatures)
+    // alive next to mpORBextractorLeft (src/Tracking.cc:171-182), so a later, smaller handle must never lower it.
+    static std::mutex mu;
+    static size_t cur[64] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && smem <= cur[dev]) return hipSuccess;
+    e = hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess && dev >= 0 && dev < 64) cur[dev] = smem;
+    return e;
 }
 void orbx_launch_blur(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, uint8_t *blur) {
     hipLaunchKernelGGL(k_blur, dim3(g.blur_tiles, B), dim3(256), 0, s, g, pyr, blur);
@@ -1966,8 +2086,12 @@ void orbx_launch_blur(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, 
 void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *pyr, const uint32_t *lvl_kp,
                           const int *lvl_count, float *lvl_angle, orbx_keypoint *kps, uint8_t *desc,
                           int *counts, int *status, int cap) {
+#ifdef ORBX_TIMING_KNOBS
     static int dbg_stop = -1;
     if (dbg_stop < 0) { const char *e = getenv("ORBX_DESC_STOP"); dbg_stop = e ? atoi(e) : 0; }
+#else
+    const int dbg_stop = 0;
+#endif
     const dim3 grid(B, (g.kp_total + DS_WPB - 1) / DS_WPB);
     if (g.fp_mode == ORBX_FP_GCC_FMA)
         hipLaunchKernelGGL(k_describe<ORBX_FP_GCC_FMA>, grid, dim3(64 * DS_WPB), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);

@@ -10,7 +10,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ORBX_HD __host__ __device__
 #else
 #define ORBX_HD

@@ -375,3 +375,47 @@ def test_randomised_parity_soak():
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "20", "11"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert "soak ok" in p.stdout
+
+
+def test_two_handles_with_different_nfeatures_interleaved():
+    """ORB-SLAM2 keeps mpIniORBextractor (2 x nFeatures) alive next to mpORBextractorLeft (src/Tracking.cc:171-182) and goes
+    back to it after a reset: the quadtree's dynamic-LDS attribute is per (function, device), so the smaller handle must not
+    lower it for the larger one."""
+    img = synth.stream(640, 480, 1, stream_id=21)[0]
+    big, small = ORBextractor(4000), ORBextractor(500)
+    ob = oracle.OracleExtractor(4000).extract(img, cap=big.max_keypoints(640, 480))
+    osm = oracle.OracleExtractor(500).extract(img, cap=small.max_keypoints(640, 480))
+    assert_frame_equal(big(img), ob, "4000 first")
+    assert_frame_equal(small(img), osm, "500")
+    assert_frame_equal(big(img), ob, "4000 after the smaller handle configured")
+    assert_frame_equal(small(img), osm, "500 again")
+
+
+def test_setup_fills_are_ordered_with_the_first_extraction():
+    """The round-1 race: configure() cleared the pyramid slab on the NULL stream, unordered with the handle's non-blocking
+    stream, and the fill could land on top of level 0 of the first batch.  The fills now run on the handle's stream; a fresh
+    handle that extracts IMMEDIATELY (large batch, so the slab fill is long) must read back every level intact -- also on a
+    caller-provided stream and after a reconfiguration to another geometry and after set_rectification."""
+    import torch
+    B = 48
+    frames = synth.stream(640, 480, B, stream_id=31)
+    orc = oracle.OracleExtractor(1000)
+    orc.extract(frames[B - 1])
+    want = [orc.level_image(l) for l in range(8)]
+    for user_stream in (False, True):
+        for rep in range(3):
+            ex = ORBextractor(1000, max_batch=B)
+            if user_stream:
+                st = torch.cuda.Stream()
+                ex.set_stream(st.cuda_stream)
+            ex.extract_batch(frames)
+            for l in range(8):
+                assert np.array_equal(ex.pyramid_level(l, B - 1), want[l]), (user_stream, rep, l)
+            assert np.array_equal(ex.pyramid_level(0, 0)[19:-19, 19:-19], frames[0])
+            # another geometry on the same handle, immediately
+            small = synth.stream(320, 240, 2, stream_id=32)
+            ex.extract_batch(small)
+            o2 = oracle.OracleExtractor(1000)
+            o2.extract(small[1])
+            for l in range(8):
+                assert np.array_equal(ex.pyramid_level(l, 1), o2.level_image(l)), ("reconfigured", user_stream, rep, l)
