@@ -210,9 +210,9 @@ def main():
                      uright=torch.zeros((B, cap), dtype=torch.float32, device=dev), depth=torch.zeros((B, cap), dtype=torch.float32, device=dev),
                      nmatch=torch.zeros(B, dtype=torch.int32, device=dev))
         bufs.append(b)
-    # descriptors + count of the last frame of the previous step (the train set of pair 0), handed from step to step
-    carry = dict(desc=torch.zeros(cap * 32, dtype=torch.uint8, device=dev), count=torch.zeros(1, dtype=torch.int32, device=dev),
-                 ready=torch.cuda.Event())
+    # slot 0 of a pipeline's buffers = descriptors + count of the last frame of the PREVIOUS step (the train set of pair 0):
+    # written by that step, after its own match, straight into the buffers of the pipeline that runs the next step
+    carry_ready = torch.cuda.Event()
     gatherer = sharding.RecordGatherer(B, cap, dev, mode=args.gather) if world > 1 else None
     torch.cuda.synchronize(dev)   # the zero fills above ran on torch's default stream; the pipelines' streams are not ordered with it
     state = {"i": 0}
@@ -230,14 +230,15 @@ def main():
                     _capi.ptr(b["kpsR"]), _capi.ptr(b["descR"]), _capi.ptr(b["countsR"]), cap, mb, mbf,
                     _capi.ptr(b["uright"]), _capi.ptr(b["depth"]), _capi.ptr(b["nmatch"])))
             else:
-                if i > 0:
-                    st.wait_event(carry["ready"])   # written at the end of step i-1 (possibly on another pipeline's stream)
-                b["desc"][0].copy_(carry["desc"]); b["counts"][0:1].copy_(carry["count"])
+                if i > 0 and NS > 1:
+                    st.wait_event(carry_ready)      # slot 0 was filled at the end of step i-1 on another pipeline's stream
                 _capi.check(L.orbx_match_bruteforce_device(
                     e.handle, B, _capi.ptr(b["desc"][1:]), _capi.ptr(b["counts"][1:]), cap * 32, _capi.ptr(b["desc"]),
                     _capi.ptr(b["counts"]), cap * 32, _capi.ptr(b["midx"]), _capi.ptr(b["mbest"]), _capi.ptr(b["msecond"]), cap))
-                carry["desc"].copy_(b["desc"][B]); carry["count"].copy_(b["counts"][B:B + 1])
-                carry["ready"].record(st)
+                nxt = bufs[(i + 1) % NS]            # (NS == 1: this pipeline's own slot 0, after the match has read it)
+                nxt["desc"][0].copy_(b["desc"][B]); nxt["counts"][0:1].copy_(b["counts"][B:B + 1])
+                if NS > 1:
+                    carry_ready.record(st)
             if gatherer is not None:
                 gatherer.gather(b["counts"][1:], b["kps"][1:], b["desc"][1:], async_op=True)
 

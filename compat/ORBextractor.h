@@ -58,14 +58,27 @@ public:
             const cv::KeyPoint *src = reinterpret_cast<const cv::KeyPoint *>(kps.data());
             keypoints.insert(keypoints.end(), src, src + n);
         }
-        // mvImagePyramid is public and read by Frame::ComputeStereoMatches (src/Frame.cc:910,1040,1072,1079)
+        // mvImagePyramid is public, but its only reader is Frame::ComputeStereoMatches (src/Frame.cc:910,1040,1072,1079), whose
+        // body compat/Frame_stereo.inl replaces by orbx_stereo_match (the pyramids stay on the device).  The eight levels
+        // (1.16 MB at 640x480) are therefore NOT copied per call; FetchPyramid() fills the member on demand.
+        pyramid_stale_ = true;
+        if (eager_pyramid_) FetchPyramid();
+    }
+
+    // Fills mvImagePyramid with the padded levels of the last frame (fork semantics, src/ORBextractor.cc:2165-2166).  For a
+    // caller that keeps the reference's own ComputeStereoMatches: call it on both extractors before that function, or
+    // construct the extractors with SetEagerPyramid(true).
+    void FetchPyramid() {
+        if (!pyramid_stale_) return;
         for (int l = 0; l < nlevels_; ++l) {
             int w, hgt, pitch;
-            orbx_pyramid_level_info(h_, l, &w, &hgt, &pitch);
+            if (orbx_pyramid_level_info(h_, l, &w, &hgt, &pitch) != ORBX_OK) return;   // nothing extracted yet
             mvImagePyramid[l].create(hgt, w, CV_8U);
             orbx_pyramid_level_copy(h_, 0, l, mvImagePyramid[l].data, (int)mvImagePyramid[l].step);
         }
+        pyramid_stale_ = false;
     }
+    void SetEagerPyramid(bool on) { eager_pyramid_ = on; }
 
     int inline GetLevels() { return nlevels_; }
     float inline GetScaleFactor() { return orbx_get_scale_factor(h_); }
@@ -76,11 +89,12 @@ public:
 
     std::vector<cv::Mat> mvImagePyramid;
 
-    orbx_handle *handle() { return h_; }   // for ORBmatcher_gpu.h
+    orbx_handle *handle() { return h_; }   // for compat/Frame_stereo.inl and ORBmatcher_gpu.h
 
 protected:
     orbx_handle *h_ = nullptr;
     int nlevels_ = 0;
+    bool pyramid_stale_ = true, eager_pyramid_ = false;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
 

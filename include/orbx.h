@@ -351,6 +351,22 @@ orbx_status orbx_undistort_keypoints_device(orbx_handle *h, int nframes, const o
                                             orbx_keypoint *d_kps_un);
 orbx_status orbx_undistort_keypoints(orbx_handle *h, const orbx_keypoint *kps, int n, const float *camera4, const float *dist,
                                      int ndist, orbx_keypoint *kps_un);
+/* Frame::AssignFeaturesToGrid + PosInGrid (src/Frame.cc:432-460, 729-745) on the device, for the keypoint buffers
+ * orbx_extract_batch_device / orbx_undistort_keypoints_device filled (records `cap` apart, cap <= 65535): per frame
+ * d_cell_begin[64 * 48 + 1] offsets (bucket c = column * 48 + row, the reference's mGrid[column][row]) into d_items[cap], the
+ * feature indices of every bucket in ascending order (= push_back order).  bounds4 = mnMinX, mnMaxX, mnMinY, mnMaxY.
+ * Asynchronous on the handle's stream: the keypoints do not leave the GPU between extraction and a gated match. */
+orbx_status orbx_grid_build_device(orbx_handle *h, int nframes, const orbx_keypoint *d_kps, const int32_t *d_counts, int cap,
+                                   const float *bounds4, int32_t *d_cell_begin, uint16_t *d_items);
+/* The primitive behind every projection-guided policy: Frame::GetFeaturesInArea (src/Frame.cc:633-717, incl. the quirk
+ * bCheckLevels = minLevel > 0 || maxLevel >= 0, :673) for nq queries against one target frame, fused with
+ * ORBmatcher::DescriptorDistance.  Host buffers.  xyr = (x, y, r) per query (r < 0: no candidates), levels = (minLevel,
+ * maxLevel) per query, qdesc = one descriptor per query.  begin[nq + 1] = offsets into items; items = the candidates of each
+ * query in the reference's visiting order (column outer, row inner, bucket order), feature index | Hamming distance << 16.
+ * *total = number of items (ORBX_CAPACITY if it exceeds items_cap; begin / total are valid then). */
+orbx_status orbx_gated_candidates(orbx_handle *h, const orbx_keypoint *target_keys, const uint8_t *target_desc, int nt,
+                                  const float *bounds4, const float *xyr, const int32_t *levels, const uint8_t *qdesc, int nq,
+                                  uint32_t *begin, uint32_t *items, int items_cap, int *total);
 /* mnMinX, mnMaxX, mnMinY, mnMaxY */
 orbx_status orbx_image_bounds(orbx_handle *h, int cols, int rows, const float *camera4, const float *dist, int ndist,
                               float *bounds4);

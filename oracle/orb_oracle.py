@@ -16,6 +16,8 @@ FP_GCC_FMA, FP_STRICT = 0, 1
 
 
 def build(force=False):
+    if os.environ.get("ORB_ORACLE_LIB"):   # another build of the same sources (sanitizer run, tests/test_sanitizers.py)
+        return os.environ["ORB_ORACLE_LIB"]
     so = os.path.join(_HERE, "liborb_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "orb_oracle_match.c", "orb_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

@@ -187,7 +187,13 @@ int orc_stereo_matches(const orc_keypoint *kL, const uint8_t *dL, int nL, const 
         const float r = 2.0f * scale[kR[iR].octave];
         const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
         for (int yi = minr; yi <= maxr; ++yi)
+#ifdef ORC_F6_UNCLAMPED
+            /* sanitizer demonstration only (tests/test_sanitizers.py, oracle/f6_demo.c): the reference's index expression
+             * vRowIndices[yi] (src/Frame.cc:934-941) on a table sized by mvImagePyramid[0].rows (:910), no bound check */
+            rcount[yi + 1]++;
+#else
             if (yi >= 0 && yi < nRows) rcount[yi + 1]++;
+#endif
     }
     for (int y = 0; y < nRows; ++y) rcount[y + 1] += rcount[y];
     int *ritems = (int *)malloc(sizeof(int) * (rcount[nRows] > 0 ? rcount[nRows] : 1));

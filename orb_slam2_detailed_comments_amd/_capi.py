@@ -93,6 +93,7 @@ SYMBOLS = [
     "orbx_search_by_bow_keyframes", "orbx_search_for_triangulation", "orbx_fuse", "orbx_fuse_sim3",
     "orbx_search_by_projection_sim3", "orbx_search_by_sim3", "orbx_search_by_projection_keyframe",
     "orbx_stereo_match_batch_device", "orbx_host_alloc", "orbx_host_free", "orbx_set_rectification", "orbx_undistort_keypoints_device",
+    "orbx_grid_build_device", "orbx_gated_candidates",
     "orbx_undistort_keypoints", "orbx_image_bounds", "orbx_vocabulary_create", "orbx_vocabulary_destroy", "orbx_bow_transform", "orbx_bow_transform_device", "orbx_bow_vectors",
 ]
 
@@ -187,6 +188,10 @@ def lib():
     L.orbx_stereo_match_batch_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp]
     L.orbx_undistort_keypoints_device.restype = i32
     L.orbx_undistort_keypoints_device.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, vp]
+    L.orbx_grid_build_device.restype = i32
+    L.orbx_grid_build_device.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp]
+    L.orbx_gated_candidates.restype = i32
+    L.orbx_gated_candidates.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp]
     L.orbx_undistort_keypoints.restype = i32; L.orbx_undistort_keypoints.argtypes = [vp, vp, i32, vp, vp, i32, vp]
     L.orbx_image_bounds.restype = i32; L.orbx_image_bounds.argtypes = [vp, i32, i32, vp, vp, i32, vp]
     L.orbx_set_rectification.restype = i32; L.orbx_set_rectification.argtypes = [vp, vp, vp, i32, i32]

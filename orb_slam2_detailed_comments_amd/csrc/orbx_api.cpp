@@ -13,6 +13,7 @@
 #include <algorithm>
 #include "orbx_internal.h"
 #include "orbx_launch.h"
+#include "orbx_gate.h"
 
 static thread_local std::string g_last_error;
 static orbx_status fail(orbx_status s, const std::string &msg) {
@@ -36,6 +37,12 @@ struct orbx_handle {
     bool host_only = false, configured = false;
     int dev = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // side stream of the batched extraction (high priority): the small pyramid levels are a chain of short, latency-bound
+    // launches; they run here, next to the issue-bound FAST kernel of the large levels on the main stream
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int fork_level = 0;       // first level whose resize + FAST run on the side stream (0 = no fork)
+    int fork_group = 0;       // first FAST group of that level
     // geometry-dependent device state
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     OrbxCell *d_cells = nullptr;
@@ -60,6 +67,7 @@ struct orbx_handle {
     int last_batch = 0;
     int mk_w = 0, mk_h = 0, mk_total = 0;   // orbx_max_keypoints cache
     void *d_match_ws = nullptr; size_t match_ws_bytes = 0;   // partial (best, second) keys of k_match
+    uint32_t *d_gate_items = nullptr; size_t gate_items_cap = 0;   // candidate lists of k_gate / distance blocks of k_block_dist (grow-only)
     // grow-only scratch arena for the host-buffer convenience entry points (match / matrix / stereo): no hipMalloc
     // on the steady-state path and nothing to leak on an error return
     uint8_t *d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
@@ -219,6 +227,18 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     if (const char *e = getenv("ORBX_FAST_LCAP")) h->fast_lcap = std::max(64, atoi(e));
     const OrbxGeom &hg = h->geom;
     hipStream_t s = h->stream;
+    // Optional fork of the batched launch sequence (run_chunk): ORBX_FORK_LEVEL = l > 0 resizes levels >= l and runs their
+    // FAST groups on the side stream next to the FAST kernel of the large levels (+1..3 % frames/s at l = 3 or 4 for 256-frame
+    // batches).  Off by default: the gain is small and kernels that share the chip have durations that no longer describe
+    // the kernel alone.
+    h->fork_level = 0;
+    if (const char *e = getenv("ORBX_FORK_LEVEL")) h->fork_level = std::min(std::max(atoi(e), 0), NL - 1);
+    h->fork_group = 0;
+    if (h->fork_level > 0) {
+        while (h->fork_group < (int)hg.fast_groups.size() && hg.cells[(size_t)hg.fast_groups[(size_t)h->fork_group].cell0].level < h->fork_level)
+            ++h->fork_group;
+        if (h->fork_group == 0 || h->fork_group >= (int)hg.fast_groups.size()) h->fork_level = 0;
+    }
     auto setup = [&]() -> hipError_t {
         hipError_t e;
 #define ORBX_TRY(expr) do { e = (expr); if (e != hipSuccess) return e; } while (0)
@@ -288,7 +308,17 @@ extern "C" orbx_status orbx_create(const orbx_params *params, orbx_handle **out)
     hipError_t e = hipSetDevice(dev);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = orbx_upload_pattern();
-    if (e != hipSuccess) { delete h; return fail(ORBX_HIP_ERROR, hipGetErrorString(e)); }
+    if (e == hipSuccess) {
+        int lo = 0, hi = 0;
+        e = hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, hi);
+        // device-scope release: the two streams exchange device memory only (a system-scope fence per record costs ~10 us)
+        unsigned evflags = hipEventDisableTiming | hipEventReleaseToDevice;
+        if (const char *ef = getenv("ORBX_EVENT_FLAGS")) evflags = (unsigned)strtoul(ef, nullptr, 0);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, evflags);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, evflags);
+    }
+    if (e != hipSuccess) { orbx_destroy(h); return fail(ORBX_HIP_ERROR, hipGetErrorString(e)); }
     h->stream = h->own_stream;
     *out = h;
     return ORBX_OK;
@@ -302,7 +332,7 @@ extern "C" void orbx_destroy(orbx_handle *h) {
         prof_drain(h);
         for (auto e : h->pool) hipEventDestroy(e);
         free_geometry_buffers(h);
-        hipFree(h->d_match_ws); hipFree(h->d_scratch); hipFree(h->d_rect);
+        hipFree(h->d_match_ws); hipFree(h->d_scratch); hipFree(h->d_rect); hipFree(h->d_gate_items);
         for (int s = 0; s < 2; ++s) {
             hipFree(h->st_in[s]); hipFree(h->st_kps[s]); hipFree(h->st_desc[s]); hipFree(h->st_cnt[s]);
             if (h->ev_in[s]) hipEventDestroy(h->ev_in[s]);
@@ -310,6 +340,9 @@ extern "C" void orbx_destroy(orbx_handle *h) {
         }
         if (h->s_in) hipStreamDestroy(h->s_in);
         if (h->s_out) hipStreamDestroy(h->s_out);
+        if (h->side_stream) { hipStreamSynchronize(h->side_stream); hipStreamDestroy(h->side_stream); }
+        if (h->ev_fork) hipEventDestroy(h->ev_fork);
+        if (h->ev_join) hipEventDestroy(h->ev_join);
         if (h->own_stream) hipStreamDestroy(h->own_stream);
     }
     delete h;
@@ -391,32 +424,59 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
     const int NL = g.nlevels;
     if (h->d_rect && (h->rect_w != W || h->rect_h != H))
         return fail(ORBX_BAD_ARGUMENT, "rectification maps were set for another image size (raw and rectified size must agree)");
-    { ProfScope ps(h, ORBX_K_MISC);
-      orbx_launch_clear(s, h->d_cand_count, B * NL, h->d_lvl_count, B * NL, d_status, B); }
+    // (no clearing launch: the per-frame status word is reset by the level-0 kernel, the per-level counters are written
+    // unconditionally by k_quadtree)
     // (A two-stream level pipeline -- FAST of level l on a low-priority stream while the main stream resizes level
     // l+1 -- was measured and rejected: 81 k frames/s against 116 k for this single in-order sequence; the cross-stream
     // event waits and the 8 small FAST launches cost more than the overlap recovers.)
     { ProfScope ps(h, ORBX_K_PYR_L0);
       if (h->d_rect) {   // cv::remap of the EuRoC rectification fused into level 0
-          orbx_launch_pyr_l0_remap(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, h->d_rect);
+          orbx_launch_pyr_l0_remap(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, h->d_rect, d_status);
       } else if (h->input_format == ORBX_FMT_GRAY8) {
-          orbx_launch_pyr_l0(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr);
+          orbx_launch_pyr_l0(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, d_status);
       } else {   // cvtColor of Tracking::GrabImage* fused into level 0
           const int nch = (h->input_format == ORBX_FMT_RGB8 || h->input_format == ORBX_FMT_BGR8) ? 3 : 4;
           const bool rgb = h->input_format == ORBX_FMT_RGB8 || h->input_format == ORBX_FMT_RGBA8;
-          orbx_launch_pyr_l0_color(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, nch, rgb ? 0 : 2, rgb ? 2 : 0);
+          orbx_launch_pyr_l0_color(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, nch, rgb ? 0 : 2, rgb ? 2 : 0, d_status);
       } }
-    for (int l = 1; l < NL; ++l) {
+    // Large batches fork after level fork_level - 1: the remaining (small) levels are resized on the high-priority side stream
+    // -- seven dependent launches of which the last four have few waves and are pure latency -- followed by their FAST
+    // groups, while the main stream runs the issue-bound FAST kernel of the large levels; joined before the quadtree.
+    const int ngroups = (int)h->geom.fast_groups.size();
+    const bool fork = h->fork_level > 0 && (long long)B * ngroups >= 16384;
+    const int l_main_end = fork ? h->fork_level : NL;
+    for (int l = 1; l < l_main_end; ++l) {
         ProfScope ps(h, ORBX_K_PYR_RESIZE);
         orbx_launch_pyr_resize(s, g, B, l, h->d_taps, h->d_pyr, h->geom.lv[l].narrow_taps && !h->resize_legacy);
     }
-    { ProfScope ps(h, ORBX_K_FAST);
-      orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, (int)h->geom.fast_groups.size(), h->d_pyr, h->d_cand,
-                            h->d_cell_count, h->max_ch, h->fast_lcap, h->fast_stop); }
+    if (fork) {
+        hipStream_t s2 = h->side_stream;
+        if (hipEventRecord(h->ev_fork, s) != hipSuccess || hipStreamWaitEvent(s2, h->ev_fork, 0) != hipSuccess)
+            return fail(ORBX_HIP_ERROR, "fork event");
+        for (int l = h->fork_level; l < NL; ++l) {
+            ProfScope ps(h, ORBX_K_PYR_RESIZE, s2);
+            orbx_launch_pyr_resize(s2, g, B, l, h->d_taps, h->d_pyr, h->geom.lv[l].narrow_taps && !h->resize_legacy);
+        }
+        { ProfScope ps(h, ORBX_K_FAST, s2);
+          orbx_launch_fast_rows(s2, g, B, h->d_cells, h->d_groups + h->fork_group, ngroups - h->fork_group, h->d_pyr, h->d_cand,
+                                h->d_cell_count, h->max_ch, h->fast_lcap, h->fast_stop); }
+        // (The quadtree of the small levels was tried on the side stream behind its FAST groups: it needs CU residency the
+        // FAST kernel of the large levels does not give up -- 201 us for 1024 workgroups that take 57 us alone -- and delays the
+        // join.  It runs after the join.)
+        { ProfScope ps(h, ORBX_K_FAST);
+          orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, h->fork_group, h->d_pyr, h->d_cand,
+                                h->d_cell_count, h->max_ch, h->fast_lcap, h->fast_stop); }
+        if (hipEventRecord(h->ev_join, s2) != hipSuccess || hipStreamWaitEvent(s, h->ev_join, 0) != hipSuccess)
+            return fail(ORBX_HIP_ERROR, "join event");
+    } else {
+        ProfScope ps(h, ORBX_K_FAST);
+        orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, ngroups, h->d_pyr, h->d_cand,
+                              h->d_cell_count, h->max_ch, h->fast_lcap, h->fast_stop);
+    }
     { ProfScope ps(h, ORBX_K_QUADTREE);
       orbx_launch_quadtree(s, g, B, h->d_cells, h->d_cand, h->d_cell_count, h->d_dense, h->d_cand_count, h->d_lvl_kp,
                            h->d_lvl_count, d_status, h->d_knode,
-                           h->ncap, h->lds_keys); }
+                           h->ncap, h->lds_keys, 0, NL); }
     // orientation (IC_Angle) is computed inside k_describe from the same LDS patch the descriptor uses
     h->blur_valid = false;  // the Gaussian is fused into k_describe; the full blurred image is only built on request
     { ProfScope ps(h, ORBX_K_DESC);
@@ -686,6 +746,135 @@ template <typename T> static T *scratch_take(orbx_handle *h, size_t count) {
 }
 static inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// ---------------------------------------------------------------- device grid + gated candidate lists (orbx_gate.h)
+static orbx_status gate_items_reserve(orbx_handle *h, size_t words) {
+    if (words <= h->gate_items_cap) return ORBX_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(h->d_gate_items); h->d_gate_items = nullptr; h->gate_items_cap = 0;
+    const size_t want = std::max(words + words / 2, (size_t)1 << 16);
+    HIPCHK(hipMalloc(&h->d_gate_items, want * sizeof(uint32_t)));
+    h->gate_items_cap = want;
+    return ORBX_OK;
+}
+static bool grid_params(float min_x, float max_x, float min_y, float max_y, DGrid &gp) {
+    if (!(max_x > min_x) || !(max_y > min_y)) return false;
+    gp.minx = min_x; gp.miny = min_y;
+    gp.winv = 64.0f / (max_x - min_x);     // mfGridElementWidthInv (src/Frame.cc:96-99): FRAME_GRID_COLS / (mnMaxX - mnMinX)
+    gp.hinv = 48.0f / (max_y - min_y);
+    return true;
+}
+
+// Frame::AssignFeaturesToGrid on the device, for the buffers orbx_extract_batch_device (or orbx_undistort_keypoints_device)
+// filled: the keypoints never leave the GPU between extraction and a gated match.
+extern "C" orbx_status orbx_grid_build_device(orbx_handle *h, int nframes, const orbx_keypoint *d_kps, const int32_t *d_counts,
+                                              int cap, const float *bounds4, int32_t *d_cell_begin, uint16_t *d_items) {
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (nframes <= 0 || !d_kps || !d_counts || cap <= 0 || cap > 65535 || !bounds4 || !d_cell_begin || !d_items)
+        return fail(ORBX_BAD_ARGUMENT, "bad argument (cap <= 65535: bucket entries are 16-bit feature indices)");
+    DGrid gp;
+    if (!grid_params(bounds4[0], bounds4[1], bounds4[2], bounds4[3], gp)) return fail(ORBX_BAD_ARGUMENT, "bad image bounds");
+    HIPCHK(hipSetDevice(h->dev));
+    { ProfScope ps(h, ORBX_K_MISC);
+      orbx_launch_grid_build(h->stream, gp, nframes, d_kps, d_counts, 0, cap, d_cell_begin, d_items); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
+    return ORBX_OK;
+}
+
+orbx_status orbx_gate_lists(orbx_handle *h, const orbx_keypoint *tkeys, const uint8_t *tdesc, int nt, float min_x, float max_x,
+                            float min_y, float max_y, const DGateQuery *q, const uint8_t *qdesc, int nq, OrbxGateLists &out) {
+    out.begin.assign((size_t)std::max(nq, 0) + 1, 0u);
+    out.items.clear();
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (nq <= 0 || nt <= 0) return ORBX_OK;
+    if (nt > 65535) return fail(ORBX_UNSUPPORTED, "more than 65535 target features");
+    DGrid gp;
+    if (!grid_params(min_x, max_x, min_y, max_y, gp)) return fail(ORBX_BAD_ARGUMENT, "bad image bounds");
+    HIPCHK(hipSetDevice(h->dev));
+    const size_t b_keys = pad256((size_t)nt * sizeof(orbx_keypoint)), b_desc = pad256((size_t)nt * 32),
+                 b_cb = pad256((size_t)(64 * 48 + 1) * sizeof(int)), b_it = pad256((size_t)nt * sizeof(uint16_t)),
+                 b_q = pad256((size_t)nq * sizeof(DGateQuery)), b_qd = pad256((size_t)nq * 32), b_beg = pad256((size_t)(nq + 1) * 4);
+    orbx_status st = scratch_reserve(h, b_keys + b_desc + b_cb + b_it + b_q + b_qd + b_beg + 256);
+    if (st != ORBX_OK) return st;
+    orbx_keypoint *dk = scratch_take<orbx_keypoint>(h, (size_t)nt);
+    uint8_t *dd = scratch_take<uint8_t>(h, (size_t)nt * 32);
+    int *dcb = scratch_take<int>(h, 64 * 48 + 1);
+    uint16_t *dit = scratch_take<uint16_t>(h, (size_t)nt);
+    DGateQuery *dq = scratch_take<DGateQuery>(h, (size_t)nq);
+    uint8_t *dqd = scratch_take<uint8_t>(h, (size_t)nq * 32);
+    uint32_t *dbeg = scratch_take<uint32_t>(h, (size_t)nq + 1);
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(dk, tkeys, (size_t)nt * sizeof(orbx_keypoint), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dd, tdesc, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * sizeof(DGateQuery), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dqd, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    { ProfScope ps(h, ORBX_K_MATCH);
+      orbx_launch_grid_build(s, gp, 1, dk, nullptr, nt, nt, dcb, dit);
+      orbx_launch_gate(s, gp, dk, dd, dcb, dit, dq, dqd, nq, dbeg, nullptr, false);   // pass 1: candidates per query
+      orbx_launch_scan_u32(s, dbeg, nq); }
+    HIPCHK(hipMemcpyAsync(out.begin.data(), dbeg, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const size_t total = out.begin[(size_t)nq];
+    if (total == 0) return ORBX_OK;
+    st = gate_items_reserve(h, total);
+    if (st != ORBX_OK) return st;
+    { ProfScope ps(h, ORBX_K_MATCH);
+      orbx_launch_gate(s, gp, dk, dd, dcb, dit, dq, dqd, nq, dbeg, h->d_gate_items, true); }   // pass 2: ordered (index, distance) lists
+    out.items.resize(total);
+    HIPCHK(hipMemcpyAsync(out.items.data(), h->d_gate_items, total * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
+    return ORBX_OK;
+}
+
+// host-buffer form of the primitive itself (tests, tools/policy_rates.py): xyr = (x, y, r) per query, levels = (min, max)
+extern "C" orbx_status orbx_gated_candidates(orbx_handle *h, const orbx_keypoint *tkeys, const uint8_t *tdesc, int nt,
+                                             const float *bounds4, const float *xyr, const int32_t *levels, const uint8_t *qdesc,
+                                             int nq, uint32_t *begin, uint32_t *items, int items_cap, int *total) {
+    if (!h || !bounds4 || nq < 0 || nt < 0 || !begin || !total || (nq > 0 && (!xyr || !levels || !qdesc)) || (nt > 0 && (!tkeys || !tdesc)))
+        return fail(ORBX_BAD_ARGUMENT, "bad argument");
+    std::vector<DGateQuery> q((size_t)nq);
+    for (int i = 0; i < nq; ++i) { q[i].x = xyr[3 * i]; q[i].y = xyr[3 * i + 1]; q[i].r = xyr[3 * i + 2]; q[i].min_level = levels[2 * i]; q[i].max_level = levels[2 * i + 1]; }
+    OrbxGateLists L;
+    orbx_status st = orbx_gate_lists(h, tkeys, tdesc, nt, bounds4[0], bounds4[1], bounds4[2], bounds4[3], q.data(), qdesc, nq, L);
+    if (st != ORBX_OK) return st;
+    memcpy(begin, L.begin.data(), ((size_t)nq + 1) * 4);
+    *total = (int)L.items.size();
+    if ((int)L.items.size() > items_cap) return fail(ORBX_CAPACITY, "candidate list capacity");
+    if (!L.items.empty() && items) memcpy(items, L.items.data(), L.items.size() * 4);
+    return ORBX_OK;
+}
+
+orbx_status orbx_block_distances(orbx_handle *h, const uint8_t *d1, int n1, const uint8_t *d2, int n2,
+                                 const std::vector<DDistRow> &rows, const std::vector<uint32_t> &col_idx, size_t total,
+                                 std::vector<uint16_t> &out) {
+    out.assign(total, 0);
+    if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
+    if (rows.empty() || total == 0) return ORBX_OK;
+    HIPCHK(hipSetDevice(h->dev));
+    orbx_status st = scratch_reserve(h, pad256((size_t)n1 * 32) + pad256((size_t)n2 * 32) + pad256(rows.size() * sizeof(DDistRow)) +
+                                            pad256(col_idx.size() * 4) + 256);
+    if (st != ORBX_OK) return st;
+    st = gate_items_reserve(h, (total + 1) / 2);
+    if (st != ORBX_OK) return st;
+    uint8_t *a = scratch_take<uint8_t>(h, (size_t)n1 * 32), *b = scratch_take<uint8_t>(h, (size_t)n2 * 32);
+    DDistRow *dr = scratch_take<DDistRow>(h, rows.size());
+    uint32_t *dc = scratch_take<uint32_t>(h, col_idx.size());
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(a, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dr, rows.data(), rows.size() * sizeof(DDistRow), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dc, col_idx.data(), col_idx.size() * 4, hipMemcpyHostToDevice, s));
+    { ProfScope ps(h, ORBX_K_MATCH);
+      orbx_launch_block_dist(s, a, b, dr, dc, (int)rows.size(), (uint16_t *)h->d_gate_items); }
+    HIPCHK(hipMemcpyAsync(out.data(), h->d_gate_items, total * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
+    return ORBX_OK;
+}
+
 // ---------------------------------------------------------------- matching
 extern "C" orbx_status orbx_match_bruteforce_device(orbx_handle *h, int npairs, const uint8_t *d_q, const int32_t *d_nq,
                                                     int64_t q_stride, const uint8_t *d_t, const int32_t *d_nt,
@@ -872,8 +1061,8 @@ extern "C" void orbx_three_maxima(const int32_t *sizes, int L, int *ind1, int *i
 }
 
 // ---------------------------------------------------------------- a13: SearchForInitialization (src/ORBmatcher.cc:570-712)
-// GPU: one Hamming matrix between the level-0 features of both frames (the only ones the policy can pair:
-// `if (level1 > 0) continue` and GetFeaturesInArea(..., level1, level1)).  Host: the sequential selection pass.
+// GPU: the grid of F2 and, per level-0 feature of F1, its window's candidates with their Hamming distances in the
+// reference's visiting order (orbx_gate_lists).  Host: the sequential selection pass over those lists.
 extern "C" orbx_status orbx_search_for_initialization(orbx_handle *h, const orbx_keypoint *k1, const uint8_t *d1, int n1,
                                                       const orbx_keypoint *k2, const uint8_t *d2, int n2,
                                                       const float *bounds4, float *prev_matched, int window,
@@ -887,37 +1076,31 @@ extern "C" orbx_status orbx_search_for_initialization(orbx_handle *h, const orbx
     *nmatches_out = 0;
     for (int i = 0; i < n1; ++i) matches12[i] = -1;
     if (n1 == 0 || n2 == 0) return ORBX_OK;
-    // level-0 subsets and the GPU distance matrix between them
-    std::vector<int> l1, l2, pos2(n2, -1);
-    for (int i = 0; i < n1; ++i) if (k1[i].octave <= 0) l1.push_back(i);
-    for (int i = 0; i < n2; ++i) if (k2[i].octave == 0) { pos2[i] = (int)l2.size(); l2.push_back(i); }
-    std::vector<uint16_t> D;
-    std::vector<int> pos1(n1, -1);
-    if (!l1.empty() && !l2.empty()) {
-        std::vector<uint8_t> q(l1.size() * 32), t(l2.size() * 32);
-        for (size_t i = 0; i < l1.size(); ++i) { memcpy(&q[i * 32], d1 + (size_t)l1[i] * 32, 32); pos1[l1[i]] = (int)i; }
-        for (size_t i = 0; i < l2.size(); ++i) memcpy(&t[i * 32], d2 + (size_t)l2[i] * 32, 32);
-        D.resize(l1.size() * l2.size());
-        orbx_status st = orbx_hamming_matrix(h, q.data(), (int)l1.size(), t.data(), (int)l2.size(), D.data());
-        if (st != ORBX_OK) return st;
+    // GPU: GetFeaturesInArea(vbPrevMatched[i1], windowSize, level1, level1) + DescriptorDistance for every level-0 feature
+    // of F1, as ordered candidate lists (k_grid_build + k_gate); features of other levels never reach the loop (:603-605)
+    std::vector<DGateQuery> gq((size_t)n1);
+    for (int i1 = 0; i1 < n1; ++i1) {
+        const int level1 = k1[i1].octave;
+        gq[i1].x = prev_matched[2 * i1]; gq[i1].y = prev_matched[2 * i1 + 1];
+        gq[i1].r = level1 > 0 ? -1.0f : (float)window;
+        gq[i1].min_level = level1; gq[i1].max_level = level1;
     }
-    orbx_grid *grid = orbx_grid_create(k2, n2, bounds4[0], bounds4[1], bounds4[2], bounds4[3]);
-    if (!grid) return fail(ORBX_BAD_ARGUMENT, "bad image bounds");
+    OrbxGateLists gl;
+    { const orbx_status st = orbx_gate_lists(h, k2, d2, n2, bounds4[0], bounds4[1], bounds4[2], bounds4[3], gq.data(), d1, n1, gl);
+      if (st != ORBX_OK) return st; }
     int nmatches = 0;
     std::vector<std::vector<int>> rotHist(HISTO);
     const float factor = HISTO / 360.0f;               // fork value (src/ORBmatcher.cc:583)
-    std::vector<int> matchedDist(n2, INT_MAX), matches21(n2, -1), cands(n2);
+    std::vector<int> matchedDist(n2, INT_MAX), matches21(n2, -1);
     for (int i1 = 0; i1 < n1; ++i1) {
         const int level1 = k1[i1].octave;
         if (level1 > 0) continue;
-        const int nc = orbx_grid_query(grid, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window, level1, level1,
-                                       cands.data(), n2);
+        const int nc = gl.count(i1);
         if (nc == 0) continue;
+        const uint32_t *cl = gl.list(i1);
         int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
         for (int c = 0; c < nc; ++c) {
-            const int i2 = cands[c];
-            // level1 == 0 here, or < 0 (never produced by the extractor): candidates then have octave >= level1 only
-            const int dist = (pos1[i1] >= 0 && pos2[i2] >= 0) ? (int)D[(size_t)pos1[i1] * l2.size() + pos2[i2]] : 256 + 1;
+            const int i2 = OrbxGateLists::idx(cl[c]), dist = OrbxGateLists::dist(cl[c]);
             if (matchedDist[i2] <= dist) continue;
             if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
             else if (dist < bestDist2) bestDist2 = dist;
@@ -949,7 +1132,6 @@ extern "C" orbx_status orbx_search_for_initialization(orbx_handle *h, const orbx
     }
     for (int i = 0; i < n1; ++i)
         if (matches12[i] >= 0) { prev_matched[2 * i] = k2[matches12[i]].x; prev_matched[2 * i + 1] = k2[matches12[i]].y; }
-    orbx_grid_destroy(grid);
     *nmatches_out = nmatches;
     return ORBX_OK;
 }
@@ -1068,10 +1250,10 @@ extern "C" orbx_status orbx_stereo_match_batch_device(orbx_handle *hl, orbx_hand
 }
 
 // ---------------------------------------------------------------- a14: SearchByProjection(Frame&, const Frame&, th, bMono)
-// (src/ORBmatcher.cc:1702-1871; caller TrackWithMotionModel src/Tracking.cc:1430,1445).  GPU: Hamming matrix between
-// the representative descriptors of the last frame's MapPoints and the current frame's descriptors.  Host: projection
-// (fp32, same operation order as the reference incl. the contraction selected by fp_mode), grid gating, the
-// occupancy rule and the rotation histogram -- all order-dependent.
+// (src/ORBmatcher.cc:1702-1871; caller TrackWithMotionModel src/Tracking.cc:1430,1445).  Host: projection (fp32, same
+// operation order as the reference incl. the contraction selected by fp_mode).  GPU: grid of the current frame, the
+// windows' candidates and their Hamming distances to the MapPoints' representative descriptors (orbx_gate_lists).
+// Host: the occupancy rule and the rotation histogram over those lists -- order-dependent.
 static inline float orbx_gemm3(const float *a, const float *b, float c) {  // cv::gemm 3x3 * 3x1 float special case
     const float t = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
     return (float)((double)t * 1.0 + (double)c * 1.0);
@@ -1091,17 +1273,6 @@ extern "C" orbx_status orbx_search_by_projection_frame(orbx_handle *h, const orb
         !last->mp_desc || !last->observations)
         return fail(ORBX_BAD_ARGUMENT, "null frame field");
     const bool fma_mode = h->p.fp_mode == ORBX_FP_GCC_FMA;
-    // GPU distances: rows = last-frame points that own a MapPoint
-    std::vector<int> rows, rpos(nl, -1);
-    for (int i = 0; i < nl; ++i) if (last->has_map_point[i]) { rpos[i] = (int)rows.size(); rows.push_back(i); }
-    std::vector<uint16_t> D;
-    if (!rows.empty()) {
-        std::vector<uint8_t> q(rows.size() * 32);
-        for (size_t r = 0; r < rows.size(); ++r) memcpy(&q[r * 32], last->mp_desc + (size_t)rows[r] * 32, 32);
-        D.resize(rows.size() * (size_t)nc);
-        orbx_status st = orbx_hamming_matrix(h, q.data(), (int)rows.size(), cur->desc, nc, D.data());
-        if (st != ORBX_OK) return st;
-    }
     float Rcw[9], tcw[3], Rlw[9], tlw[3], twc[3], tlc[3];
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) { Rcw[3 * r + c] = cur->Tcw[4 * r + c]; Rlw[3 * r + c] = last->Tcw[4 * r + c]; }
@@ -1113,13 +1284,12 @@ extern "C" orbx_status orbx_search_by_projection_frame(orbx_handle *h, const orb
     }
     for (int r = 0; r < 3; ++r) tlc[r] = orbx_gemm3(&Rlw[3 * r], twc, tlw[r]);
     const bool bForward = tlc[2] > cur->mb && !mono, bBackward = -tlc[2] > cur->mb && !mono;
-    orbx_grid *grid = orbx_grid_create(cur->keys_un, nc, cur->min_x, cur->max_x, cur->min_y, cur->max_y);
-    if (!grid) return fail(ORBX_BAD_ARGUMENT, "bad image bounds");
-    std::vector<std::vector<int>> rotHist(HISTO);
-    const float factor = HISTO / 360.0f;  // fork value (src/ORBmatcher.cc:1713)
-    std::vector<int> cands(nc);
-    int nmatches = 0;
+    // pass 1 (host, independent of the selection state): project every MapPoint of the last frame, derive its window and
+    // octave band (:1742-1783).  pass 2 (GPU): the windows' candidates + Hamming distances.  pass 3 (host): the selection.
+    std::vector<DGateQuery> gq((size_t)nl);
+    std::vector<float> q_invz((size_t)nl, 0.f), q_u((size_t)nl, 0.f);
     for (int i = 0; i < nl; ++i) {
+        gq[i].r = -1.0f; gq[i].x = gq[i].y = 0.f; gq[i].min_level = gq[i].max_level = -1;
         if (!last->has_map_point[i]) continue;
         float pc[3];
         for (int r = 0; r < 3; ++r) pc[r] = orbx_gemm3(&Rcw[3 * r], last->world_pos + 3 * (size_t)i, tcw[r]);
@@ -1131,20 +1301,34 @@ extern "C" orbx_status orbx_search_by_projection_frame(orbx_handle *h, const orb
         if (u < cur->min_x || u > cur->max_x || v < cur->min_y || v > cur->max_y) continue;
         const int oct = last->keys_un[i].octave;
         if (oct < 0 || oct >= h->p.nlevels) continue;
-        const float radius = th * h->tab.scale[oct];
-        const int ncand = bForward ? orbx_grid_query(grid, u, v, radius, oct, -1, cands.data(), nc)
-                          : bBackward ? orbx_grid_query(grid, u, v, radius, 0, oct, cands.data(), nc)
-                                      : orbx_grid_query(grid, u, v, radius, oct - 1, oct + 1, cands.data(), nc);
+        gq[i].x = u; gq[i].y = v; gq[i].r = th * h->tab.scale[oct];
+        if (bForward) { gq[i].min_level = oct; gq[i].max_level = -1; }
+        else if (bBackward) { gq[i].min_level = 0; gq[i].max_level = oct; }
+        else { gq[i].min_level = oct - 1; gq[i].max_level = oct + 1; }
+        q_invz[i] = invzc; q_u[i] = u;
+    }
+    OrbxGateLists gl;
+    { const orbx_status st = orbx_gate_lists(h, cur->keys_un, cur->desc, nc, cur->min_x, cur->max_x, cur->min_y, cur->max_y,
+                                             gq.data(), last->mp_desc, nl, gl);
+      if (st != ORBX_OK) return st; }
+    std::vector<std::vector<int>> rotHist(HISTO);
+    const float factor = HISTO / 360.0f;  // fork value (src/ORBmatcher.cc:1713)
+    int nmatches = 0;
+    for (int i = 0; i < nl; ++i) {
+        if (gq[i].r < 0.f) continue;
+        const float invzc = q_invz[i], u = q_u[i], radius = gq[i].r;
+        const int ncand = gl.count(i);
         if (ncand == 0) continue;
+        const uint32_t *cl = gl.list(i);
         int bestDist = 256, bestIdx2 = -1;
         for (int c = 0; c < ncand; ++c) {
-            const int i2 = cands[c];
+            const int i2 = OrbxGateLists::idx(cl[c]);
             if (matched_last[i2] >= 0 && last->observations[matched_last[i2]] > 0) continue;
             if (cur->u_right[i2] > 0) {
                 const float ur = fma_mode ? std::fmaf(-cur->mbf, invzc, u) : u - cur->mbf * invzc;
                 if (fabsf(ur - cur->u_right[i2]) > radius) continue;
             }
-            const int dist = (int)D[(size_t)rpos[i] * nc + i2];
+            const int dist = OrbxGateLists::dist(cl[c]);
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }
         if (bestDist <= TH_HIGH_) {
@@ -1167,15 +1351,14 @@ extern "C" orbx_status orbx_search_by_projection_frame(orbx_handle *h, const orb
             if (i != i1 && i != i2 && i != i3)
                 for (int idx2 : rotHist[i]) { matched_last[idx2] = -1; nmatches--; }
     }
-    orbx_grid_destroy(grid);
     *nmatches_out = nmatches;
     return ORBX_OK;
 }
 
 // ---------------------------------------------------------------- (f)1: SearchByProjection(Frame&, vector<MapPoint*>&, th)
 // (src/ORBmatcher.cc:69-184, RadiusByViewingCos :187-194; caller Tracking::SearchLocalPoints src/Tracking.cc:1953) --
-// the largest per-frame matcher load in steady state.  GPU: Hamming matrix between the descriptors of the MapPoints
-// in view and the frame's descriptors.  Host: grid gating, occupancy rule, level-aware ratio test (order-dependent).
+// the largest per-frame matcher load in steady state.  GPU: the frame's grid, every in-view MapPoint's window candidates
+// and their Hamming distances (orbx_gate_lists).  Host: occupancy rule, level-aware ratio test (order-dependent).
 extern "C" orbx_status orbx_search_by_projection_mappoints(orbx_handle *h, const orbx_frame_view *frame,
                                                            const int32_t *frame_observations,
                                                            const orbx_mappoint_view *mps, float th, float nnratio,
@@ -1189,34 +1372,40 @@ extern "C" orbx_status orbx_search_by_projection_mappoints(orbx_handle *h, const
     if (!frame->keys_un || !frame->desc || !frame->u_right || !frame_observations || !mps->in_view || !mps->proj ||
         !mps->level || !mps->view_cos || !mps->desc || !mps->observations)
         return fail(ORBX_BAD_ARGUMENT, "null field");
-    std::vector<int> rows, rpos(nmp, -1);
-    for (int i = 0; i < nmp; ++i) if (mps->in_view[i]) { rpos[i] = (int)rows.size(); rows.push_back(i); }
-    if (rows.empty()) return ORBX_OK;
-    std::vector<uint8_t> q(rows.size() * 32);
-    for (size_t r = 0; r < rows.size(); ++r) memcpy(&q[r * 32], mps->desc + (size_t)rows[r] * 32, 32);
-    std::vector<uint16_t> D(rows.size() * (size_t)nf);
-    orbx_status st = orbx_hamming_matrix(h, q.data(), (int)rows.size(), frame->desc, nf, D.data());
-    if (st != ORBX_OK) return st;
-    orbx_grid *grid = orbx_grid_create(frame->keys_un, nf, frame->min_x, frame->max_x, frame->min_y, frame->max_y);
-    if (!grid) return fail(ORBX_BAD_ARGUMENT, "bad image bounds");
-    std::vector<int> occ(frame_observations, frame_observations + nf), cands(nf);
+    std::vector<DGateQuery> gq((size_t)nmp);
+    bool any = false;
     const bool bFactor = th != 1.0;
-    int nmatches = 0;
     for (int iMP = 0; iMP < nmp; ++iMP) {
+        gq[iMP].x = mps->proj[3 * iMP]; gq[iMP].y = mps->proj[3 * iMP + 1]; gq[iMP].r = -1.0f;
+        gq[iMP].min_level = gq[iMP].max_level = -1;
         if (!mps->in_view[iMP]) continue;
         const int lvl = mps->level[iMP];
         if (lvl < 0 || lvl >= h->p.nlevels) continue;
         float r = mps->view_cos[iMP] > 0.998 ? 2.5f : 4.0f;
         if (bFactor) r *= th;
-        const float radius = r * h->tab.scale[lvl];
-        const int nc = orbx_grid_query(grid, mps->proj[3 * iMP], mps->proj[3 * iMP + 1], radius, lvl - 1, lvl, cands.data(), nf);
+        gq[iMP].r = r * h->tab.scale[lvl];
+        gq[iMP].min_level = lvl - 1; gq[iMP].max_level = lvl;
+        any = true;
+    }
+    if (!any) return ORBX_OK;
+    OrbxGateLists gl;
+    { const orbx_status st = orbx_gate_lists(h, frame->keys_un, frame->desc, nf, frame->min_x, frame->max_x, frame->min_y,
+                                             frame->max_y, gq.data(), mps->desc, nmp, gl);
+      if (st != ORBX_OK) return st; }
+    std::vector<int> occ(frame_observations, frame_observations + nf);
+    int nmatches = 0;
+    for (int iMP = 0; iMP < nmp; ++iMP) {
+        if (gq[iMP].r < 0.f) continue;
+        const float radius = gq[iMP].r;
+        const int nc = gl.count(iMP);
         if (nc == 0) continue;
+        const uint32_t *cl = gl.list(iMP);
         int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
         for (int c = 0; c < nc; ++c) {
-            const int idx = cands[c];
+            const int idx = OrbxGateLists::idx(cl[c]);
             if (occ[idx] > 0) continue;
             if (frame->u_right[idx] > 0 && fabsf(mps->proj[3 * iMP + 2] - frame->u_right[idx]) > radius) continue;
-            const int dist = (int)D[(size_t)rpos[iMP] * nf + idx];
+            const int dist = OrbxGateLists::dist(cl[c]);
             if (dist < bestDist) {
                 bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = frame->keys_un[idx].octave; bestIdx = idx;
             } else if (dist < bestDist2) {
@@ -1230,7 +1419,6 @@ extern "C" orbx_status orbx_search_by_projection_mappoints(orbx_handle *h, const
             nmatches++;
         }
     }
-    orbx_grid_destroy(grid);
     *nmatches_out = nmatches;
     return ORBX_OK;
 }

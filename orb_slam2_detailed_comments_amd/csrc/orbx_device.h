@@ -36,6 +36,13 @@ struct OrbxStereoGeom {
     long long off[ORBX_MAX_LEVELS];
 };
 
+// Frame grid (64 x 48 buckets over [minx, maxx) x [miny, maxy)): mfGridElementWidthInv / HeightInv of src/Frame.cc:96-99
+struct DGrid { float minx, miny, winv, hinv; };
+// one GetFeaturesInArea query (src/Frame.cc:633-717): centre, radius (negative = query switched off), level band
+struct DGateQuery { float x, y, r; int min_level, max_level; };
+// one row of a BoW-guided distance block: descriptor q of set 1 against ncol features of set 2
+struct DDistRow { uint32_t q, col_begin, ncol, out_off; };
+
 #define ORBX_WAVE 64
 
 __device__ __forceinline__ int orbx_reflect101(int i, int n) {

@@ -27,7 +27,8 @@
 #define QT_FF 1
 #endif
 __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restrict__ imgs, int W, int H, int stride,
-                                                long long frame_stride, uint8_t *__restrict__ pyr, int xe) {
+                                                long long frame_stride, uint8_t *__restrict__ pyr, int xe,
+                                                int *__restrict__ status) {
     // block = 64 x 4 threads, thread = L0_ROWS rows.  Blocks with blockIdx.x < gridDim.x - 1 copy the interior
     // columns [32, xe) with dword-aligned loads + funnel shifts (16 pixels per thread and row); the LAST block column
     // owns the two border strips [0, 32) and [xe, pitch) where reflect-101 reverses the byte order (byte gathers).
@@ -38,6 +39,9 @@ __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restri
 #else
     const int f = blockIdx.z, bx = blockIdx.x, by = blockIdx.y, nbx = gridDim.x;
 #endif
+    // the per-frame status word (atomicMax'ed by the later kernels of the batch) is reset here: level 0 is the first kernel of
+    // every batch, which saves a separate clearing launch in front of it
+    if (bx == 0 && by == 0 && threadIdx.x == 0 && threadIdx.y == 0) status[f] = 0;
     const int Y0 = (by * 4 + threadIdx.y) * L0_ROWS;
     if (Y0 >= L.ph) return;
     const uint8_t *img = imgs + (long long)f * frame_stride;
@@ -86,11 +90,12 @@ __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restri
 // OpenCV 3.2 8-bit formula: gray = (R*4899 + G*9617 + B*1868 + 8192) >> 14.  thread = 4 padded pixels.
 __global__ __launch_bounds__(256) void k_pyr_l0_color(DGeom g, const uint8_t *__restrict__ imgs, int W, int H, int stride,
                                                       long long frame_stride, uint8_t *__restrict__ pyr, int nch,
-                                                      int r_off, int b_off) {
+                                                      int r_off, int b_off, int *__restrict__ status) {
     const DLevel &L = g.lv[0];
     const int X = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int Y = blockIdx.y * 4 + threadIdx.y;
     const int f = blockIdx.z;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) status[f] = 0;
     if (X >= L.pw || Y >= L.ph) return;
     const uint8_t *src = imgs + (long long)f * frame_stride + (long long)orbx_reflect101(Y - ORBX_EDGE, H) * stride;
     uint32_t v = 0;
@@ -115,11 +120,12 @@ __global__ __launch_bounds__(256) void k_pyr_l0_color(DGeom g, const uint8_t *__
 // rect entry: .x = ix | iy << 16 (int16 each), .y = fy << 5 | fx.  thread = 4 padded pixels.
 __global__ __launch_bounds__(256) void k_pyr_l0_remap(DGeom g, const uint8_t *__restrict__ imgs, int W, int H, int stride,
                                                       long long frame_stride, uint8_t *__restrict__ pyr,
-                                                      const uint2 *__restrict__ rect) {
+                                                      const uint2 *__restrict__ rect, int *__restrict__ status) {
     const DLevel &L = g.lv[0];
     const int X = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int Y = blockIdx.y * 4 + threadIdx.y;
     const int f = blockIdx.z;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) status[f] = 0;
     if (X >= L.pw || Y >= L.ph) return;
     const uint8_t *src = imgs + (long long)f * frame_stride;
     const uint2 *mrow = rect + (long long)orbx_reflect101(Y - ORBX_EDGE, H) * W;
@@ -379,25 +385,13 @@ __device__ __forceinline__ void orbx_wave_sync() {
 //     LDS footprint is independent of how many pixels pass;
 //   * NMS walks the corner list when every corner of the group fitted it, otherwise it rescans the score map.
 // ------------------------------------------------------------------------------------------------
-#ifndef FR_GLDS
-#define FR_GLDS 1       // 1: the tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass);
-                        // 0: the round-1 staging (12-byte register loads of the NEXT tile, written to LDS one group later)
-#endif
 #ifndef FR_TP
-#if FR_GLDS
-#define FR_TP 80        // LDS tile pitch = 5 x 16 bytes: one LDS-DMA instruction (64 lanes x 16 B, lane-linear) covers 12.8 rows
-#else
 #define FR_TP 76        // LDS tile pitch: 64 interior columns + 6 ring + 3 alignment bytes -> 19 dwords (odd: rows spread over all banks)
 #endif
-#endif
-// bytes of the LDS tile region for `rows` tile rows: whole LDS-DMA instructions (1 KiB each) in the FR_GLDS layout
-__host__ __device__ static inline int fr_tile_bytes(int rows) {
-#if FR_GLDS
-    return ((rows * (FR_TP / 16) + 63) / 64) * 1024;
-#else
-    return rows * FR_TP;
-#endif
-}
+// (Staging the tile by LDS-DMA -- global_load_lds_dwordx4 at pitch 80, no VGPR round trip, no ds_write pass -- was built and
+// measured in round 2: bit-exact, but 408-414 us against 402 us for the register-prefetch staging below, also with the next
+// tile requested before the NMS of the current one: the staging instructions are ~5 % of the kernel's issue slots and the
+// register prefetch hides the load latency better than a wait on vmcnt does.  Not kept; git history has it.)
 #ifndef FR_WPS
 #define FR_WPS 4
 #endif
@@ -541,7 +535,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
 #endif
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
     uint32_t *s_tile = (uint32_t *)fast_smem;
-    uint8_t *s_score = fast_smem + fr_tile_bytes(rows);
+    uint8_t *s_score = fast_smem + rows * FR_TP;
     uint16_t *s_list = (uint16_t *)(s_score + rows * FR_TP);   // lcap entries + one private dummy dword per lane
     uint16_t *s_corn = s_list + lcap + 128;
     const int lane = threadIdx.x;
@@ -550,23 +544,6 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     // is processed, so the global-load latency is never waited for
     const int g0 = blockIdx.y * gpw;
     const int ng = min(gpw, ngroups - g0);
-#if FR_GLDS
-    // staging by LDS-DMA: chunk c = 64 k + lane of instruction k is 16 bytes, tile row c / 5, byte column 16 (c % 5); the
-    // LDS image is lane-linear (M0 base + 16 lane), which IS the row-major tile at pitch 80.  Per tile and instruction the
-    // lane's source offset is min(row, last row) * pitch + column + the tile origin: two vector instructions, and the data
-    // never passes through VGPRs (round 1 staged 5 twelve-byte loads per lane through registers and ~15 ds_write_b32).
-    OrbxFastGroup grp_n = groups[g0];
-    OrbxCell c0_n = cells[grp_n.cell0], c1_n = cells[grp_n.cell0 + grp_n.ncell - 1];
-    const uint8_t *fbase = pyr + (long long)f * g.pyr_bytes;
-    uint32_t ck_row[4], ck_col[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t c = 64u * k + (uint32_t)lane;
-        ck_row[k] = (c * 13108u) >> 16;          // c / 5 for c < 16384
-        ck_col[k] = 16u * (c - 5u * ck_row[k]);
-    }
-    const uint32_t lds_tile = (uint32_t)(uintptr_t)(fr_lds_u16 *)s_tile;   // LDS byte address of the tile (wave-uniform)
-#else
     // staging: a lane loads 12 bytes (one load, a third of the address arithmetic and of the load instructions of a
     // dword per lane), 7 lanes cover the 19 dwords of a tile row, 9 rows per step, 5 steps = 45 rows in registers.
     // Row offsets are 32-bit adds from the first row's offset, clamped to the cell's last row; the address is the
@@ -591,7 +568,6 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         }                                                                                                                 \
     }
     FR_PREFETCH()
-#endif
   for (int gi = 0; gi < ng; ++gi) {
     const OrbxFastGroup grp = grp_n;
     const OrbxCell c0 = c0_n, c1 = c1_n;
@@ -599,38 +575,6 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     const int tw = c1.x0 + c1.cw - c0.x0, th_rows = c0.ch;
     const int niw = tw - 6;                                   // interior columns of the group (<= 64)
     const int iw0 = grp.ncell == 2 ? c0.cw - 6 : 64;
-#if FR_GLDS
-    // ---- stage the tile: LDS-DMA straight from the pyramid level (the previous group's tile reads have all returned: their
-    // results were consumed), score map cleared while the loads are in flight, then wait for them
-    {
-        const uint8_t *src = fbase + L.off + (long long)__mul24((int)c0.y0, L.pitch) + (c0.x0 & ~3);   // wave-uniform
-        const uint32_t last = (uint32_t)(th_rows - 1);
-        const int ninstr = (th_rows * (FR_TP / 16) + 63) >> 6;
-        for (int k = 0; k < ninstr; ++k) {
-            uint32_t row, col;
-            if (k < 4) { row = k == 0 ? ck_row[0] : k == 1 ? ck_row[1] : k == 2 ? ck_row[2] : ck_row[3];
-                         col = k == 0 ? ck_col[0] : k == 1 ? ck_col[1] : k == 2 ? ck_col[2] : ck_col[3]; }
-            else { const uint32_t c = 64u * k + (uint32_t)lane; row = (c * 13108u) >> 16; col = 16u * (c - 5u * row); }
-            const uint32_t off = __umul24(min(row, last), (uint32_t)L.pitch) + col;
-            uint32_t keep;
-            // M0 = LDS destination of this instruction; saved / restored inside the statement (the compiler owns M0)
-            asm volatile("s_mov_b32 %0, m0\n\t"
-                         "s_mov_b32 m0, %3\n\t"
-                         "s_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, %2\n\t"
-                         "s_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(off), "s"(src), "s"(lds_tile + 1024u * (uint32_t)k)
-                         : "memory");
-        }
-        for (int i = lane; i < (th_rows * (FR_TP / 4) + 3) / 4; i += 64) ((uint4 *)s_score)[i] = make_uint4(0, 0, 0, 0);
-        if (gi + 1 < ng) {
-            grp_n = groups[g0 + gi + 1];
-            c0_n = cells[grp_n.cell0]; c1_n = cells[grp_n.cell0 + grp_n.ncell - 1];
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA writes are counted in vmcnt (the compiler does not see them)
-    }
-#else
     // ---- stage the tile: prefetched registers -> LDS
     {
         const int xa = c0.x0 & ~3;
@@ -663,7 +607,6 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         c0_n = cells[grp_n.cell0]; c1_n = cells[grp_n.cell0 + grp_n.ncell - 1];
         FR_PREFETCH()
     }
-#endif
     FrCtx cx;
     cx.tile = (const uint8_t *)s_tile + (c0.x0 & 3);
     cx.score = s_score;
@@ -817,7 +760,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
 // Selection (:1387-1413) = max response, first in emission order, via one 64-bit LDS atomicMax per key.
 // ------------------------------------------------------------------------------------------------
 #ifndef QT_THREADS
-#define QT_THREADS 512
+#define QT_THREADS 256   // round 2: with the key slots sized for 4 workgroups per CU, 256 threads beat 512 (99 vs 117 us per 256 frames)
 #endif
 
 struct QtShared {
@@ -873,14 +816,14 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
                                                         int *__restrict__ cand_count,
                                                         uint32_t *__restrict__ lvl_kp, int *__restrict__ lvl_count,
                                                         int *__restrict__ status, uint16_t *__restrict__ knode_glob,
-                                                        int ncap, int lds_keys) {
+                                                        int ncap, int lds_keys, int level_begin) {
     extern __shared__ __attribute__((aligned(16))) uint8_t qt_smem[];
     // grid: frame fastest, level 0 (the most keys) dispatched first.  With the level fastest, workgroup id % 8 = level for
     // the usual 8 levels: one XCD would get every level-0 workgroup and another every level-7 one.
 #if QT_FF
-    const int level = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
+    const int level = level_begin + blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
 #else
-    const int level = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int level = level_begin + blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
 #endif
     const DLevel &L = g.lv[level];
     const int N = L.nfeat;
@@ -1279,6 +1222,9 @@ __constant__ uint32_t c_orient_w[64][12];
 #define DS_WPB 1   // waves (= keypoints) per block.  Nothing is shared between the waves of a block; one-wave blocks let the
                    // dispatcher place every wave as soon as any SIMD has room: 282 us against 299 (4 waves) and 372 (8)
 #endif
+#ifndef DS_KPW
+#define DS_KPW 1   // keypoints per wave, processed one after the other
+#endif
 #ifndef DS_WPS
 #define DS_WPS 7   // waves per SIMD the register allocation must allow (LDS admits 7 blocks of 4 waves per CU)
 #endif
@@ -1287,44 +1233,14 @@ __constant__ uint32_t c_orient_w[64][12];
 // LDS round trips, and resident waves are what hides them.)
 // FPM (fp_mode) is a template constant: as a run-time value it costs a scalar branch and both code paths in each of the 8 taps
 typedef const __attribute__((address_space(3))) uint16_t *orbx_lds_u16p;
+// one keypoint = one pass of a wave over its two LDS buffers
 template <int FPM>
-__global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
-                                                  const uint32_t *__restrict__ lvl_kp,
-                                                  const int *__restrict__ lvl_count,
-                                                  float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
-                                                  uint8_t *__restrict__ desc, int *__restrict__ counts,
-                                                  int *__restrict__ status, int cap, int dbg_stop) {
-    // dbg_stop (ORBX_DESC_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS): 1 = after staging, 2 = after orientation,
-    // 3 = after the row pass.  The shipped library pins it to 0.
-#ifndef ORBX_TIMING_KNOBS
-    dbg_stop = 0;
-#endif
-    __shared__ uint32_t s_patch[DS_WPB][DS_W * DS_PP / 4 + 4];
-    __shared__ __attribute__((aligned(16))) uint16_t s_h[DS_WPB][DS_W * DS_HC];
-    // one wave per keypoint, waves indexed by dense OUTPUT position (level-major order of operator(), :2066-2082).
-    // The wave index is wave-uniform (which the compiler cannot see): with it scalar, the level search and the position
-    // load run on the scalar unit.
-    const int lane = threadIdx.x & 63, wv_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int f = blockIdx.x;   // frame fastest: one frame's patches stay in one XCD's L2
-    const int oi = blockIdx.y * DS_WPB + wv_id;
-    const int *lc = lvl_count + f * g.nlevels;
-    int total = 0, level = 0, slot = oi;
-#pragma unroll
-    for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
-        if (l < g.nlevels) {
-            if (oi >= total) { level = l; slot = g.lv[l].kp_begin + (oi - total); }
-            total += lc[l];
-        }
-    }
-    if (blockIdx.y == 0 && wv_id == 0 && lane == 0) {
-        counts[f] = min(total, cap);
-        if (total > cap) atomicMax(&status[f], (int)ORBX_CAPACITY);
-    }
-    if (oi >= min(total, cap) || dbg_stop == 4) return;
+__device__ __forceinline__ void ds_one_keypoint(const DGeom &g, const uint8_t *__restrict__ pyr, const uint32_t *__restrict__ lvl_kp,
+                                                float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
+                                                uint8_t *__restrict__ desc, int cap, int dbg_stop, int f, int oi, int level, int slot,
+                                                int lane, uint32_t *patch, uint16_t *hrow) {
     const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];
     const int4 pat = c_pattern_lane[lane];
-    uint32_t *patch = s_patch[wv_id];
-    uint16_t *hrow = s_h[wv_id];
     const DLevel &L = g.lv[level];
     const int x = (int)(pos & 0xfff) + (ORBX_EDGE - 3), y = (int)((pos >> 12) & 0xfff) + (ORBX_EDGE - 3);
     const uint8_t *img = pyr + (long long)f * g.pyr_bytes + L.off;
@@ -1511,6 +1427,56 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
             kp.class_id = -1;
             kps[(long long)f * cap + oi] = kp;
         }
+    }
+}
+
+template <int FPM>
+__global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
+                                                  const uint32_t *__restrict__ lvl_kp,
+                                                  const int *__restrict__ lvl_count,
+                                                  float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
+                                                  uint8_t *__restrict__ desc, int *__restrict__ counts,
+                                                  int *__restrict__ status, int cap, int dbg_stop) {
+    // dbg_stop (ORBX_DESC_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS): 1 = after staging, 2 = after orientation,
+    // 3 = after the row pass.  The shipped library pins it to 0.
+#ifndef ORBX_TIMING_KNOBS
+    dbg_stop = 0;
+#endif
+    __shared__ uint32_t s_patch[DS_WPB][DS_W * DS_PP / 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[DS_WPB][DS_W * DS_HC];
+    // one wave per keypoint, waves indexed by dense OUTPUT position (level-major order of operator(), :2066-2082).
+    // The wave index is wave-uniform (which the compiler cannot see): with it scalar, the level search and the position
+    // load run on the scalar unit.
+    const int lane = threadIdx.x & 63, wv_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int f = blockIdx.x;   // frame fastest: one frame's patches stay in one XCD's L2
+    // DS_KPW consecutive output positions per wave, one after the other through the same LDS buffers: the launch of 258 k
+    // one-wave workgroups per 256 frames is itself ~60 us of this kernel (wave launch rate), and a second keypoint costs no
+    // registers (nothing of the next keypoint is prefetched -- that variant lost to the occupancy it costs)
+    const int oi0 = (blockIdx.y * DS_WPB + wv_id) * DS_KPW;
+    const int *lc = lvl_count + f * g.nlevels;
+    int total = 0;
+    int lend[ORBX_MAX_LEVELS];   // running totals (scalar registers)
+#pragma unroll
+    for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
+        if (l < g.nlevels) total += lc[l];
+        lend[l] = total;
+    }
+    if (blockIdx.y == 0 && wv_id == 0 && lane == 0) {
+        counts[f] = min(total, cap);
+        if (total > cap) atomicMax(&status[f], (int)ORBX_CAPACITY);
+    }
+    if (dbg_stop == 4) return;
+    uint32_t *patch = s_patch[wv_id];
+    uint16_t *hrow = s_h[wv_id];
+    for (int kk = 0; kk < DS_KPW; ++kk) {
+        const int oi = oi0 + kk;
+        if (oi >= min(total, cap)) return;
+        int level = 0, slot = oi;
+#pragma unroll
+        for (int l = 1; l < ORBX_MAX_LEVELS; ++l)
+            if (l < g.nlevels && oi >= lend[l - 1]) { level = l; slot = g.lv[l].kp_begin + (oi - lend[l - 1]); }
+        if (kk > 0) orbx_wave_sync();   // the previous keypoint's LDS reads are done before its buffers are overwritten
+        ds_one_keypoint<FPM>(g, pyr, lvl_kp, lvl_angle, kps, desc, cap, dbg_stop, f, oi, level, slot, lane, patch, hrow);
     }
 }
 
@@ -1932,6 +1898,166 @@ __global__ __launch_bounds__(256) void k_undistort(DUndist u, const orbx_keypoin
     out[(long long)f * cap + i] = kp;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K11: the Frame grid on the device.  k_grid_build = Frame::AssignFeaturesToGrid + PosInGrid (reference src/Frame.cc:432-460,
+// 729-745): 64 x 48 buckets, every bucket lists its features in ascending feature index (push_back order).  k_gate =
+// Frame::GetFeaturesInArea (:633-717) for one query per wave, fused with DescriptorDistance: the cells are walked in the
+// reference's order (ix outer, iy inner -- for one ix the buckets iy0..iy1 are one contiguous range of the CSR item
+// array), the radius / level tests (incl. the quirk `bCheckLevels = minLevel > 0 || maxLevel >= 0`, :673) run per lane,
+// survivors are ballot-compacted in visiting order and leave as (feature index | Hamming distance << 16).  The policies'
+// order-dependent bookkeeping reads these short lists on the host instead of a dense nq x nt distance matrix.
+// ------------------------------------------------------------------------------------------------
+#define GR_COLS 64
+#define GR_ROWS 48
+#define GR_CELLS (GR_COLS * GR_ROWS)
+__device__ __forceinline__ int gr_cell_of(const DGrid &gp, const orbx_keypoint &kp) {
+    const int px = (int)roundf((kp.x - gp.minx) * gp.winv), py = (int)roundf((kp.y - gp.miny) * gp.hinv);   // C round(): half away from zero
+    return (px < 0 || px >= GR_COLS || py < 0 || py >= GR_ROWS) ? -1 : px * GR_ROWS + py;
+}
+__global__ __launch_bounds__(1024) void k_grid_build(DGrid gp, const orbx_keypoint *__restrict__ kps, const int *__restrict__ counts,
+                                                     int fixed_n, int cap, int *__restrict__ cell_begin, uint16_t *__restrict__ items) {
+    __shared__ int s_cnt[GR_CELLS];
+    __shared__ int s_part[1024];
+    const long long f = blockIdx.x;
+    const int t = threadIdx.x;
+    const int n = counts ? min(counts[f], cap) : fixed_n;
+    const orbx_keypoint *k = kps + f * cap;
+    for (int c = t; c < GR_CELLS; c += 1024) s_cnt[c] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        const int c = gr_cell_of(gp, k[i]);
+        if (c >= 0) atomicAdd(&s_cnt[c], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the 3072 buckets: three per thread, Hillis-Steele over the thread sums
+    const int c0 = 3 * t;
+    const int a0 = s_cnt[c0], a1 = s_cnt[c0 + 1], a2 = s_cnt[c0 + 2];
+    const int sum = a0 + a1 + a2;
+    s_part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = t >= o ? s_part[t - o] : 0;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    int run = s_part[t] - sum;
+    int *cb = cell_begin + f * (GR_CELLS + 1);
+    cb[c0] = run; s_cnt[c0] = run; run += a0;
+    cb[c0 + 1] = run; s_cnt[c0 + 1] = run; run += a1;
+    cb[c0 + 2] = run; s_cnt[c0 + 2] = run;
+    if (t == 1023) cb[GR_CELLS] = s_part[1023];
+    __syncthreads();
+    uint16_t *it = items + f * cap;
+    for (int i = t; i < n; i += 1024) {
+        const int c = gr_cell_of(gp, k[i]);
+        if (c >= 0) it[atomicAdd(&s_cnt[c], 1)] = (uint16_t)i;
+    }
+    __syncthreads();
+    // the atomics filled every bucket in arrival order: restore feature order (buckets hold a handful of entries)
+    for (int c = t; c < GR_CELLS; c += 1024) {
+        const int b = cb[c], e = s_cnt[c];
+        for (int i = b + 1; i < e; ++i) {
+            const uint16_t v = it[i];
+            int j = i - 1;
+            while (j >= b && it[j] > v) { it[j + 1] = it[j]; --j; }
+            it[j + 1] = v;
+        }
+    }
+}
+
+// one wave per query; FILL = false: count the candidates, FILL = true: write them at out_begin[query]
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_gate(DGrid gp, const orbx_keypoint *__restrict__ kps, const uint8_t *__restrict__ desc,
+                                              const int *__restrict__ cell_begin, const uint16_t *__restrict__ items,
+                                              const DGateQuery *__restrict__ q, const uint8_t *__restrict__ qdesc, int nq,
+                                              uint32_t *__restrict__ out_begin, uint32_t *__restrict__ out_items) {
+    const int lane = threadIdx.x & 63;
+    const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (qi >= nq) return;
+    const DGateQuery Q = q[qi];
+    int n = 0;
+    uint32_t base = 0;
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+    if (FILL) {
+        base = out_begin[qi];
+        const uint4 *qp = (const uint4 *)(qdesc + (long long)qi * 32);
+        qa = qp[0]; qb = qp[1];
+    }
+    // GetFeaturesInArea's cell range (:643-668); a negative radius switches the query off
+    const int x0 = max(0, (int)floorf((Q.x - gp.minx - Q.r) * gp.winv));
+    const int x1 = min(GR_COLS - 1, (int)ceilf((Q.x - gp.minx + Q.r) * gp.winv));
+    const int y0 = max(0, (int)floorf((Q.y - gp.miny - Q.r) * gp.hinv));
+    const int y1 = min(GR_ROWS - 1, (int)ceilf((Q.y - gp.miny + Q.r) * gp.hinv));
+    if (Q.r >= 0.f && x0 < GR_COLS && x1 >= 0 && y0 < GR_ROWS && y1 >= 0) {
+        const bool check = (Q.min_level > 0) || (Q.max_level >= 0);
+        for (int ix = x0; ix <= x1; ++ix) {
+            const int b = cell_begin[ix * GR_ROWS + y0], e = cell_begin[ix * GR_ROWS + y1 + 1];
+            for (int j0 = b; j0 < e; j0 += 64) {
+                const int j = j0 + lane;
+                bool pass = false;
+                int i2 = 0;
+                if (j < e) {
+                    i2 = items[j];
+                    const orbx_keypoint kp = kps[i2];
+                    pass = fabsf(kp.x - Q.x) < Q.r && fabsf(kp.y - Q.y) < Q.r;
+                    if (check) pass = pass && !(kp.octave < Q.min_level) && !(Q.max_level >= 0 && kp.octave > Q.max_level);
+                }
+                const unsigned long long m = orbx_ballot(pass);
+                if (FILL && pass) {
+                    const uint4 *tp = (const uint4 *)(desc + (long long)i2 * 32);
+                    const uint4 ta = tp[0], tb = tp[1];
+                    const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                                       __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+                    out_items[base + (uint32_t)n + (uint32_t)orbx_wave_rank(m)] = (uint32_t)i2 | (d << 16);
+                }
+                n += __popcll(m);
+            }
+        }
+    }
+    if (!FILL && lane == 0) out_begin[qi] = (uint32_t)n;
+}
+
+// exclusive prefix sum of a[0..n) in place, a[n] = total; one workgroup
+__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, int n) {
+    __shared__ uint32_t s_part[1024];
+    const int t = threadIdx.x;
+    const int chunk = (n + 1023) / 1024, b = min(t * chunk, n), e = min(b + chunk, n);
+    uint32_t sum = 0;
+    for (int i = b; i < e; ++i) sum += a[i];
+    s_part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = t >= o ? s_part[t - o] : 0u;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[t] - sum;
+    for (int i = b; i < e; ++i) { const uint32_t c = a[i]; a[i] = run; run += c; }
+    if (t == 1023) a[n] = s_part[1023];
+}
+
+// Hamming distances of the BoW-guided policies: row r pairs descriptor rows[r].q of the first set with the features
+// col_idx[col_begin .. col_begin + ncol) of the second set (the features under the same vocabulary node, in the reference's
+// visiting order); distances leave as uint16 at out[out_off ..).  One wave per row.
+__global__ __launch_bounds__(256) void k_block_dist(const uint8_t *__restrict__ d1, const uint8_t *__restrict__ d2,
+                                                    const DDistRow *__restrict__ rows, const uint32_t *__restrict__ col_idx, int nrows,
+                                                    uint16_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (r >= nrows) return;
+    const DDistRow R = rows[r];
+    const uint4 *qp = (const uint4 *)(d1 + (long long)R.q * 32);
+    const uint4 qa = qp[0], qb = qp[1];
+    for (uint32_t j = lane; j < R.ncol; j += 64) {
+        const uint4 *tp = (const uint4 *)(d2 + (long long)col_idx[R.col_begin + j] * 32);
+        const uint4 ta = tp[0], tb = tp[1];
+        out[R.out_off + j] = (uint16_t)(__popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                                        __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w));
+    }
+}
+
 __global__ void k_clear(int *a, int na, int *b, int nb, int *c, int nc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < na) a[i] = 0;
@@ -1986,7 +2112,7 @@ void orbx_launch_clear(hipStream_t s, int *a, int na, int *b, int nb, int *c, in
     hipLaunchKernelGGL(k_clear, dim3((n + 255) / 256), dim3(256), 0, s, a, na, b, nb, c, nc);
 }
 void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
-                        long long frame_stride, uint8_t *pyr) {
+                        long long frame_stride, uint8_t *pyr, int *status) {
     const DLevel &L = g.lv[0];
     // interior columns [32, xe): the 20-byte aligned window of every 16-pixel chunk stays inside the source row
     int xe = 32;
@@ -1997,19 +2123,19 @@ void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *img
 #else
     dim3 grid(icols + 1, (L.ph + 4 * L0_ROWS - 1) / (4 * L0_ROWS), B);
 #endif
-    hipLaunchKernelGGL(k_pyr_l0, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, xe);
+    hipLaunchKernelGGL(k_pyr_l0, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, xe, status);
 }
 void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
-                              long long frame_stride, uint8_t *pyr, int nch, int r_off, int b_off) {
+                              long long frame_stride, uint8_t *pyr, int nch, int r_off, int b_off, int *status) {
     const DLevel &L = g.lv[0];
     dim3 grid((L.pw + 255) / 256, (L.ph + 3) / 4, B);
-    hipLaunchKernelGGL(k_pyr_l0_color, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, nch, r_off, b_off);
+    hipLaunchKernelGGL(k_pyr_l0_color, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, nch, r_off, b_off, status);
 }
 void orbx_launch_pyr_l0_remap(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
-                              long long frame_stride, uint8_t *pyr, const uint2 *rect) {
+                              long long frame_stride, uint8_t *pyr, const uint2 *rect, int *status) {
     const DLevel &L = g.lv[0];
     dim3 grid((L.pw + 255) / 256, (L.ph + 3) / 4, B);
-    hipLaunchKernelGGL(k_pyr_l0_remap, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, rect);
+    hipLaunchKernelGGL(k_pyr_l0_remap, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, rect, status);
 }
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr, bool narrow) {
     const DLevel &L = g.lv[level];
@@ -2034,7 +2160,7 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
     if (ngroups <= 0) return;
     lcap = (max(lcap, 64) + 1) & ~1;
     max_ch = (max_ch + 3) & ~3;   // tile and score map sizes multiples of 16 bytes
-    const size_t smem = (size_t)fr_tile_bytes(max_ch) + (size_t)max_ch * FR_TP + (size_t)4 * lcap + 256;
+    const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256;
     // groups per wave: FR_GPW when the launch has waves to spare (the second group's tile is prefetched while the first
     // is processed); one per wave for small batches, where the serial length of a wave is what the caller waits for
     const int gpw = (long long)B * ngroups >= 16384 ? FR_GPW : 1;
@@ -2061,10 +2187,11 @@ void orbx_launch_bow_transform(hipStream_t s, int B, int max_n, const int *child
 }
 void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
                           const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,
-                          int *status, uint16_t *knode_glob, int ncap, int lds_keys) {
+                          int *status, uint16_t *knode_glob, int ncap, int lds_keys, int level_begin, int level_count) {
+    if (level_count <= 0) return;
     const size_t smem = orbx_quadtree_smem(ncap, lds_keys);
-    hipLaunchKernelGGL(k_quadtree, QT_FF ? dim3(B, g.nlevels) : dim3(g.nlevels, B), dim3(QT_THREADS), smem, s, g, cells, slots, cell_count, dense,
-                       cand_count, lvl_kp, lvl_count, status, knode_glob, ncap, lds_keys);
+    hipLaunchKernelGGL(k_quadtree, QT_FF ? dim3(B, level_count) : dim3(level_count, B), dim3(QT_THREADS), smem, s, g, cells, slots, cell_count, dense,
+                       cand_count, lvl_kp, lvl_count, status, knode_glob, ncap, lds_keys, level_begin);
 }
 hipError_t orbx_quadtree_prepare(size_t smem) {
     // The attribute belongs to (function, device), not to a handle: ORB-SLAM2 itself keeps mpIniORBextractor (2 x nFeatures)
@@ -2092,11 +2219,31 @@ void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *p
 #else
     const int dbg_stop = 0;
 #endif
-    const dim3 grid(B, (g.kp_total + DS_WPB - 1) / DS_WPB);
+    const dim3 grid(B, (g.kp_total + DS_WPB * DS_KPW - 1) / (DS_WPB * DS_KPW));
     if (g.fp_mode == ORBX_FP_GCC_FMA)
         hipLaunchKernelGGL(k_describe<ORBX_FP_GCC_FMA>, grid, dim3(64 * DS_WPB), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
     else
         hipLaunchKernelGGL(k_describe<ORBX_FP_STRICT>, grid, dim3(64 * DS_WPB), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
+}
+void orbx_launch_grid_build(hipStream_t s, const DGrid &gp, int nframes, const orbx_keypoint *kps, const int *counts, int fixed_n,
+                            int cap, int *cell_begin, uint16_t *items) {
+    if (nframes <= 0) return;
+    hipLaunchKernelGGL(k_grid_build, dim3(nframes), dim3(1024), 0, s, gp, kps, counts, fixed_n, cap, cell_begin, items);
+}
+void orbx_launch_gate(hipStream_t s, const DGrid &gp, const orbx_keypoint *kps, const uint8_t *desc, const int *cell_begin,
+                      const uint16_t *items, const DGateQuery *q, const uint8_t *qdesc, int nq, uint32_t *begin, uint32_t *out_items,
+                      bool fill) {
+    if (nq <= 0) return;
+    if (fill) hipLaunchKernelGGL(k_gate<true>, dim3((nq + 3) / 4), dim3(256), 0, s, gp, kps, desc, cell_begin, items, q, qdesc, nq, begin, out_items);
+    else hipLaunchKernelGGL(k_gate<false>, dim3((nq + 3) / 4), dim3(256), 0, s, gp, kps, desc, cell_begin, items, q, qdesc, nq, begin, out_items);
+}
+void orbx_launch_scan_u32(hipStream_t s, uint32_t *a, int n) {
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, a, n);
+}
+void orbx_launch_block_dist(hipStream_t s, const uint8_t *d1, const uint8_t *d2, const DDistRow *rows, const uint32_t *col_idx,
+                            int nrows, uint16_t *out) {
+    if (nrows <= 0) return;
+    hipLaunchKernelGGL(k_block_dist, dim3((nrows + 3) / 4), dim3(256), 0, s, d1, d2, rows, col_idx, nrows, out);
 }
 size_t orbx_match_workspace_bytes(int npairs, int out_stride) { return (size_t)npairs * MT_SPLIT * out_stride * sizeof(uint2); }
 void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,

@@ -2,17 +2,19 @@
 //   SearchByBoW(KeyFrame*, Frame&)        src/ORBmatcher.cc:248-410   (relocalisation / TrackReferenceKeyFrame)
 //   SearchByBoW(KeyFrame*, KeyFrame*)     src/ORBmatcher.cc:722-866   (loop-closure candidates)
 //   SearchForTriangulation                src/ORBmatcher.cc:879-1087  (LocalMapping::CreateNewMapPoints)
-// GPU: one Hamming matrix between the two descriptor sets (k_hamming_matrix through orbx_hamming_matrix).
-// Host: the merge walk over the two FeatureVectors and the order-dependent selection (a feature of the second set can
-// only be taken once, in the order the reference visits them), exactly as the reference runs it.
+// Host: the merge walk over the two FeatureVectors (which pairs can meet: the features under a common vocabulary node).
+// GPU: the Hamming distances of exactly those pairs, one block per common node (k_block_dist through orbx_block_distances;
+// round 1 computed the dense n1 x n2 matrix and copied it to the host).
+// Host: the order-dependent selection (a feature of the second set can only be taken once, in the order the reference visits
+// them), exactly as the reference runs it.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 #include "orbx_internal.h"
+#include "orbx_gate.h"
 
-extern "C" orbx_status orbx_hamming_matrix(orbx_handle *h, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *dist);
 extern "C" void orbx_three_maxima(const int32_t *sizes, int L, int *ind1, int *ind2, int *ind3);
 orbx_status orbx_fail(orbx_status s, const std::string &msg);   // orbx_api.cpp: records orbx_last_error()
 int orbx_handle_fp_mode(const orbx_handle *h);
@@ -63,6 +65,36 @@ template <class F> void walk_common_nodes(const orbx_featvec_view &f1, const orb
         else { while (b < f2.n_nodes && f2.node_id[b] < f1.node_id[a]) ++b; }
     }
 }
+
+// distance blocks of the common nodes: for node pair (a, b) block[(ik - begin_a) * nb + (jf - begin_b)]
+struct NodeBlocks {
+    std::vector<size_t> off_a;            // per node a of f1: offset of its block (SIZE_MAX = no common node)
+    std::vector<int> nb_a;                // per node a: number of features of f2's node
+    std::vector<uint16_t> D;
+    orbx_status build(orbx_handle *h, const uint8_t *d1, int n1, const orbx_featvec_view &f1, const uint8_t *d2, int n2,
+                      const orbx_featvec_view &f2) {
+        off_a.assign((size_t)std::max(f1.n_nodes, 0), (size_t)-1);
+        nb_a.assign((size_t)std::max(f1.n_nodes, 0), 0);
+        std::vector<DDistRow> rows;
+        std::vector<uint32_t> cols;
+        size_t total = 0;
+        walk_common_nodes(f1, f2, [&](int a, int b) {
+            const int na = f1.begin[a + 1] - f1.begin[a], nb = f2.begin[b + 1] - f2.begin[b];
+            if (na <= 0 || nb <= 0) return;
+            off_a[(size_t)a] = total; nb_a[(size_t)a] = nb;
+            const uint32_t cb = (uint32_t)cols.size();
+            for (int j = f2.begin[b]; j < f2.begin[b + 1]; ++j) cols.push_back(f2.index[j]);
+            for (int i = f1.begin[a]; i < f1.begin[a + 1]; ++i) {
+                DDistRow r; r.q = f1.index[i]; r.col_begin = cb; r.ncol = (uint32_t)nb; r.out_off = (uint32_t)total;
+                rows.push_back(r);
+                total += (size_t)nb;
+            }
+        });
+        if (total > 0xffffffffull) return orbx_fail(ORBX_UNSUPPORTED, "too many descriptor pairs under common vocabulary nodes");
+        return orbx_block_distances(h, d1, n1, d2, n2, rows, cols, total, D);
+    }
+    const uint16_t *row(int a, int i_in_node) const { return D.data() + off_a[(size_t)a] + (size_t)i_in_node * (size_t)nb_a[(size_t)a]; }
+};
 }  // namespace
 
 extern "C" orbx_status orbx_search_by_bow_keyframe_frame(orbx_handle *h, const orbx_keyframe_view *kf,
@@ -77,22 +109,23 @@ extern "C" orbx_status orbx_search_by_bow_keyframe_frame(orbx_handle *h, const o
     *nmatches_out = 0;
     for (int i = 0; i < nf; ++i) matched_kf[i] = -1;
     if (nf == 0 || kf->n == 0) return ORBX_OK;
-    std::vector<uint16_t> D((size_t)kf->n * nf);
-    orbx_status st = orbx_hamming_matrix(h, kf->desc, kf->n, f_desc, nf, D.data());
+    const orbx_featvec_view &fk = kf->feat_vec;
+    NodeBlocks nbk;
+    orbx_status st = nbk.build(h, kf->desc, kf->n, fk, f_desc, nf, *f_fv);
     if (st != ORBX_OK) return st;
     int nmatches = 0;
     RotHist hist;
-    const orbx_featvec_view &fk = kf->feat_vec;
     walk_common_nodes(fk, *f_fv, [&](int a, int b) {
         for (int ik = fk.begin[a]; ik < fk.begin[a + 1]; ++ik) {
             const uint32_t iKF = fk.index[ik];
             if (!kf->has_map_point[iKF]) continue;
             int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
-            const uint16_t *row = &D[(size_t)iKF * nf];
+            if (f_fv->begin[b + 1] == f_fv->begin[b]) continue;
+            const uint16_t *row = nbk.row(a, ik - fk.begin[a]);
             for (int jf = f_fv->begin[b]; jf < f_fv->begin[b + 1]; ++jf) {
                 const uint32_t iF = f_fv->index[jf];
                 if (matched_kf[iF] >= 0) continue;
-                const int dist = row[iF];
+                const int dist = row[jf - f_fv->begin[b]];
                 if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)iF; }
                 else if (dist < bestDist2) bestDist2 = dist;
             }
@@ -121,23 +154,24 @@ extern "C" orbx_status orbx_search_by_bow_keyframes(orbx_handle *h, const orbx_k
     for (int i = 0; i < kf1->n; ++i) matches12[i] = -1;
     if (kf1->n == 0 || kf2->n == 0) return ORBX_OK;
     const int n2 = kf2->n;
-    std::vector<uint16_t> D((size_t)kf1->n * n2);
-    orbx_status st = orbx_hamming_matrix(h, kf1->desc, kf1->n, kf2->desc, n2, D.data());
+    const orbx_featvec_view &f1 = kf1->feat_vec, &f2 = kf2->feat_vec;
+    NodeBlocks nbk;
+    orbx_status st = nbk.build(h, kf1->desc, kf1->n, f1, kf2->desc, n2, f2);
     if (st != ORBX_OK) return st;
     int nmatches = 0;
     RotHist hist;
     std::vector<uint8_t> matched2((size_t)n2, 0);
-    const orbx_featvec_view &f1 = kf1->feat_vec, &f2 = kf2->feat_vec;
     walk_common_nodes(f1, f2, [&](int a, int b) {
         for (int p = f1.begin[a]; p < f1.begin[a + 1]; ++p) {
             const uint32_t i1 = f1.index[p];
             if (!kf1->has_map_point[i1]) continue;
             int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
-            const uint16_t *row = &D[(size_t)i1 * n2];
+            if (f2.begin[b + 1] == f2.begin[b]) continue;
+            const uint16_t *row = nbk.row(a, p - f1.begin[a]);
             for (int q = f2.begin[b]; q < f2.begin[b + 1]; ++q) {
                 const uint32_t i2 = f2.index[q];
                 if (matched2[i2] || !kf2->has_map_point[i2]) continue;
-                const int dist = row[i2];
+                const int dist = row[q - f2.begin[b]];
                 if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)i2; }
                 else if (dist < bestDist2) bestDist2 = dist;
             }
@@ -191,13 +225,13 @@ extern "C" orbx_status orbx_search_for_triangulation(orbx_handle *h, const orbx_
     if (kf1->n == 0 || kf2->n == 0) return ORBX_OK;
     const int n2 = kf2->n;
     const bool fma_mode = orbx_handle_fp_mode(h) == ORBX_FP_GCC_FMA;
-    std::vector<uint16_t> D((size_t)kf1->n * n2);
-    orbx_status st = orbx_hamming_matrix(h, kf1->desc, kf1->n, kf2->desc, n2, D.data());
+    const orbx_featvec_view &f1 = kf1->feat_vec, &f2 = kf2->feat_vec;
+    NodeBlocks nbk;
+    orbx_status st = nbk.build(h, kf1->desc, kf1->n, f1, kf2->desc, n2, f2);
     if (st != ORBX_OK) return st;
     int nmatches = 0;
     RotHist hist;
     std::vector<uint8_t> matched2((size_t)n2, 0);
-    const orbx_featvec_view &f1 = kf1->feat_vec, &f2 = kf2->feat_vec;
     walk_common_nodes(f1, f2, [&](int a, int b) {
         for (int p = f1.begin[a]; p < f1.begin[a + 1]; ++p) {
             const uint32_t i1 = f1.index[p];
@@ -206,13 +240,14 @@ extern "C" orbx_status orbx_search_for_triangulation(orbx_handle *h, const orbx_
             if (only_stereo && !stereo1) continue;
             const orbx_keypoint &kp1 = kf1->keys_un[i1];
             int bestDist = TH_LOW_, bestIdx2 = -1;
-            const uint16_t *row = &D[(size_t)i1 * n2];
+            if (f2.begin[b + 1] == f2.begin[b]) continue;
+            const uint16_t *row = nbk.row(a, p - f1.begin[a]);
             for (int q = f2.begin[b]; q < f2.begin[b + 1]; ++q) {
                 const uint32_t i2 = f2.index[q];
                 if (matched2[i2] || kf2->has_map_point[i2]) continue;
                 const bool stereo2 = kf2->u_right[i2] >= 0;
                 if (only_stereo && !stereo2) continue;
-                const int dist = row[i2];
+                const int dist = row[q - f2.begin[b]];
                 if (dist > TH_LOW_ || dist > bestDist) continue;
                 const orbx_keypoint &kp2 = kf2->keys_un[i2];
                 if (!stereo1 && !stereo2) {                              // too close to the epipole (:996-1003)
@@ -242,12 +277,10 @@ extern "C" orbx_status orbx_search_for_triangulation(orbx_handle *h, const orbx_
 // The pose algebra in front of them is cv::Mat / cv::norm / MapPoint::PredictScale code that stays in the maintainer's
 // shim (it IS the reference's code); the entry points start where the reference holds, per MapPoint, the flag "passed every
 // geometric test", the projection, the predicted level and the representative descriptor.
-// GPU: one Hamming matrix (points x features).  Host: GetFeaturesInArea, level band, chi2 gate, first-best selection and
-// the order-dependent bookkeeping, as the reference runs them.
+// GPU: the target's grid, GetFeaturesInArea per projected point and the Hamming distances of its candidates, in the
+// reference's visiting order (orbx_gate_lists; round 1 copied a dense points x features matrix to the host).
+// Host: level band, chi2 gate, first-best selection and the order-dependent bookkeeping, as the reference runs them.
 // ================================================================================================================
-extern "C" orbx_grid *orbx_grid_create(const orbx_keypoint *kps, int n, float min_x, float max_x, float min_y, float max_y);
-extern "C" void orbx_grid_destroy(orbx_grid *g);
-extern "C" int orbx_grid_query(const orbx_grid *g, float x, float y, float r, int min_level, int max_level, int32_t *out, int cap);
 
 namespace {
 const int TH_HIGH_ = 100;
@@ -259,11 +292,19 @@ bool points_ok(const orbx_projected_points *p) {
     return p && p->n >= 0 && (p->n == 0 || (p->valid && p->uv && p->level && p->desc));
 }
 
-// distances of every point descriptor to every target descriptor, row-major [np][nk]
-orbx_status point_matrix(orbx_handle *h, const orbx_projected_points *p, const orbx_target_view *t, std::vector<uint16_t> &D) {
-    D.assign((size_t)p->n * t->n, 0);
-    if (p->n == 0 || t->n == 0) return ORBX_OK;
-    return orbx_hamming_matrix(h, p->desc, p->n, t->desc, t->n, D.data());
+// GetFeaturesInArea(u, v, radius, lo, hi) + DescriptorDistance of every valid point against the target's features, on the
+// GPU (orbx_gate_lists): `radius_of(i)` is the policy's window, (lo, hi) its level arguments (-1, -1 = the plain overload)
+template <class R, class LV>
+orbx_status point_lists(orbx_handle *h, const orbx_target_view *t, const orbx_projected_points *p, R &&radius_of, LV &&levels_of,
+                        OrbxGateLists &gl) {
+    std::vector<DGateQuery> gq((size_t)p->n);
+    for (int i = 0; i < p->n; ++i) {
+        gq[i].x = p->uv[2 * i]; gq[i].y = p->uv[2 * i + 1]; gq[i].r = -1.0f; gq[i].min_level = gq[i].max_level = -1;
+        if (!p->valid[i]) continue;
+        gq[i].r = radius_of(i);
+        levels_of(i, gq[i].min_level, gq[i].max_level);
+    }
+    return orbx_gate_lists(h, t->keys_un, t->desc, t->n, t->min_x, t->max_x, t->min_y, t->max_y, gq.data(), p->desc, p->n, gl);
 }
 
 // level band [pred - 1, pred], no chi2 gate; `taken` as the reference's vpMatched (NULL = not used)
@@ -272,26 +313,22 @@ orbx_status project_and_pick(orbx_handle *h, const orbx_target_view *t, const or
     *count = 0;
     for (int i = 0; i < p->n; ++i) best_idx[i] = -1;
     if (p->n == 0 || t->n == 0) return ORBX_OK;
-    std::vector<uint16_t> D;
-    orbx_status st = point_matrix(h, p, t, D);
+    OrbxGateLists gl;
+    orbx_status st = point_lists(h, t, p, [&](int i) { return th * t->scale_factors[p->level[i]]; }, [](int, int &, int &) {}, gl);
     if (st != ORBX_OK) return st;
-    orbx_grid *g = orbx_grid_create(t->keys_un, t->n, t->min_x, t->max_x, t->min_y, t->max_y);
-    if (!g) return orbx_fail(ORBX_BAD_ARGUMENT, "bad image bounds");
-    std::vector<int32_t> cands((size_t)t->n);
     int n = 0;
     for (int i = 0; i < p->n; ++i) {
         if (!p->valid[i]) continue;
         const int pred = p->level[i];
-        const float radius = th * t->scale_factors[pred];
-        const int nc = orbx_grid_query(g, p->uv[2 * i], p->uv[2 * i + 1], radius, -1, -1, cands.data(), t->n);
+        const int nc = gl.count(i);
+        const uint32_t *cl = gl.list(i);
         int bestDist = init_best, bestIdx = -1;
-        const uint16_t *row = &D[(size_t)i * t->n];
         for (int c = 0; c < nc; ++c) {
-            const int idx = cands[c];
+            const int idx = OrbxGateLists::idx(cl[c]);
             if (taken && taken[idx]) continue;
             const int lvl = t->keys_un[idx].octave;
             if (lvl < pred - 1 || lvl > pred) continue;
-            const int dist = row[idx];
+            const int dist = OrbxGateLists::dist(cl[c]);
             if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
         }
         if (bestDist <= max_dist) {
@@ -300,7 +337,6 @@ orbx_status project_and_pick(orbx_handle *h, const orbx_target_view *t, const or
             n++;
         }
     }
-    orbx_grid_destroy(g);
     *count = n;
     return ORBX_OK;
 }
@@ -316,23 +352,19 @@ extern "C" orbx_status orbx_fuse(orbx_handle *h, const orbx_target_view *kf, con
     for (int i = 0; i < pts->n; ++i) best_idx[i] = -1;
     if (pts->n == 0 || kf->n == 0) return ORBX_OK;
     const bool fma_mode = orbx_handle_fp_mode(h) == ORBX_FP_GCC_FMA;
-    std::vector<uint16_t> D;
-    orbx_status st = point_matrix(h, pts, kf, D);
+    OrbxGateLists gl;
+    orbx_status st = point_lists(h, kf, pts, [&](int i) { return th * kf->scale_factors[pts->level[i]]; }, [](int, int &, int &) {}, gl);
     if (st != ORBX_OK) return st;
-    orbx_grid *g = orbx_grid_create(kf->keys_un, kf->n, kf->min_x, kf->max_x, kf->min_y, kf->max_y);
-    if (!g) return orbx_fail(ORBX_BAD_ARGUMENT, "bad image bounds");
-    std::vector<int32_t> cands((size_t)kf->n);
     int n = 0;
     for (int i = 0; i < pts->n; ++i) {
         if (!pts->valid[i]) continue;
         const float u = pts->uv[2 * i], v = pts->uv[2 * i + 1];
         const int pred = pts->level[i];
-        const float radius = th * kf->scale_factors[pred];
-        const int nc = orbx_grid_query(g, u, v, radius, -1, -1, cands.data(), kf->n);
+        const int nc = gl.count(i);
+        const uint32_t *cl = gl.list(i);
         int bestDist = 256, bestIdx = -1;
-        const uint16_t *row = &D[(size_t)i * kf->n];
         for (int c = 0; c < nc; ++c) {
-            const int idx = cands[c];
+            const int idx = OrbxGateLists::idx(cl[c]);
             const orbx_keypoint &kp = kf->keys_un[idx];
             const int lvl = kp.octave;
             if (lvl < pred - 1 || lvl > pred) continue;
@@ -345,12 +377,11 @@ extern "C" orbx_status orbx_fuse(orbx_handle *h, const orbx_target_view *kf, con
                 const float e2 = fma_mode ? std::fmaf(ex, ex, ey * ey) : ex * ex + ey * ey;
                 if ((double)(e2 * kf->inv_level_sigma2[lvl]) > 5.99) continue;
             }
-            const int dist = row[idx];
+            const int dist = OrbxGateLists::dist(cl[c]);
             if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
         }
         if (bestDist <= TH_LOW_) { best_idx[i] = bestIdx; n++; }
     }
-    orbx_grid_destroy(g);
     *nfused = n;
     return ORBX_OK;
 }
@@ -404,25 +435,21 @@ extern "C" orbx_status orbx_search_by_projection_keyframe(orbx_handle *h, const 
     *nmatches_out = 0;
     for (int i = 0; i < cur->n; ++i) matched_point[i] = -1;
     if (pts->n == 0 || cur->n == 0) return ORBX_OK;
-    std::vector<uint16_t> D;
-    orbx_status st = point_matrix(h, pts, cur, D);
+    OrbxGateLists gl;
+    orbx_status st = point_lists(h, cur, pts, [&](int i) { return th * cur->scale_factors[pts->level[i]]; },
+                                 [&](int i, int &lo, int &hi) { lo = pts->level[i] - 1; hi = pts->level[i] + 1; }, gl);
     if (st != ORBX_OK) return st;
-    orbx_grid *g = orbx_grid_create(cur->keys_un, cur->n, cur->min_x, cur->max_x, cur->min_y, cur->max_y);
-    if (!g) return orbx_fail(ORBX_BAD_ARGUMENT, "bad image bounds");
-    std::vector<int32_t> cands((size_t)cur->n);
     RotHist hist;
     int nmatches = 0;
     for (int i = 0; i < pts->n; ++i) {
         if (!pts->valid[i]) continue;
-        const int pred = pts->level[i];
-        const float radius = th * cur->scale_factors[pred];
-        const int nc = orbx_grid_query(g, pts->uv[2 * i], pts->uv[2 * i + 1], radius, pred - 1, pred + 1, cands.data(), cur->n);
+        const int nc = gl.count(i);
+        const uint32_t *cl = gl.list(i);
         int bestDist = 256, bestIdx2 = -1;
-        const uint16_t *row = &D[(size_t)i * cur->n];
         for (int c = 0; c < nc; ++c) {
-            const int i2 = cands[c];
+            const int i2 = OrbxGateLists::idx(cl[c]);
             if (cur_has_map_point[i2]) continue;
-            const int dist = row[i2];
+            const int dist = OrbxGateLists::dist(cl[c]);
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }
         if (bestDist <= orb_dist) {
@@ -434,7 +461,6 @@ extern "C" orbx_status orbx_search_by_projection_keyframe(orbx_handle *h, const 
     }
     if (check_orientation)
         hist.reject_minor([&](int i2) { cur_has_map_point[i2] = 0; matched_point[i2] = -1; nmatches--; });
-    orbx_grid_destroy(g);
     *nmatches_out = nmatches;
     return ORBX_OK;
 }

@@ -419,3 +419,19 @@ def test_setup_fills_are_ordered_with_the_first_extraction():
             o2.extract(small[1])
             for l in range(8):
                 assert np.array_equal(ex.pyramid_level(l, 1), o2.level_image(l)), ("reconfigured", user_stream, rep, l)
+
+
+def test_forked_launch_sequence_is_bit_exact(monkeypatch):
+    """ORBX_FORK_LEVEL = l: the resizes of levels >= l and their FAST groups run on the handle's side stream next to the FAST
+    kernel of the large levels (csrc/orbx_api.cpp run_chunk).  Large batches only (>= 16384 FAST groups), so 40 frames here."""
+    B = 40
+    frames = synth.stream(640, 480, B, stream_id=51)
+    orc = oracle.OracleExtractor(1000)
+    want = {f: orc.extract(frames[f]) for f in (0, 17, B - 1)}
+    for lvl in ("3", "4", "6"):
+        monkeypatch.setenv("ORBX_FORK_LEVEL", lvl)
+        ex = ORBextractor(1000, max_batch=B)
+        for rep in range(2):
+            res = ex.extract_batch(frames)
+            for f, w in want.items():
+                assert_frame_equal(res[f], w, f"fork level {lvl} rep {rep} frame {f}")

@@ -185,3 +185,65 @@ def test_randomised_policy_soak():
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_policies.py"), "15", "7"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "policy soak ok" in p.stdout
+
+
+def test_device_grid_and_gated_candidates_equal_host_grid():
+    """k_grid_build / k_gate (Frame::AssignFeaturesToGrid, GetFeaturesInArea + DescriptorDistance on the device) against the
+    oracle's grid query and descriptor distance: same candidates, same ORDER, same distances -- for windows inside, across and
+    outside the image, every level-argument form incl. the `minLevel > 0 || maxLevel >= 0` quirk (src/Frame.cc:673), empty
+    queries, and the device-resident grid of a batch."""
+    import ctypes as C
+    import torch
+    from orb_slam2_detailed_comments_amd import _capi
+    from orb_slam2_detailed_comments_amd._capi import ptr
+    L = _capi.lib()
+    img = synth.stream(640, 480, 2, stream_id=41)
+    ex = ORBextractor(1000, max_batch=2)
+    (k0, d0), (k1, d1) = ex.extract_batch(img)
+    bounds = np.array([0.0, 640.0, 0.0, 480.0], np.float32)
+    rng = np.random.default_rng(5)
+    nq = 700
+    xyr = np.zeros((nq, 3), np.float32); lv = np.zeros((nq, 2), np.int32)
+    xyr[:, 0] = rng.uniform(-60, 700, nq); xyr[:, 1] = rng.uniform(-60, 540, nq)
+    xyr[:, 2] = rng.choice([3.0, 7.5, 15.0, 40.0, 100.0, 250.0, -1.0], nq)
+    forms = [(-1, -1), (0, 0), (0, 3), (2, -1), (1, 2), (-1, 4), (5, 7), (0, -1)]
+    lv[:] = np.array([forms[i % len(forms)] for i in range(nq)], np.int32)
+    qd = d1[rng.integers(0, len(d1), nq)].copy()
+    begin = np.zeros(nq + 1, np.uint32); items = np.zeros(1 << 20, np.uint32); tot = C.c_int(0)
+    _capi.check(L.orbx_gated_candidates(ex.handle, ptr(k0), ptr(d0), len(k0), ptr(bounds), ptr(xyr), ptr(lv), ptr(qd), nq,
+                                        ptr(begin), ptr(items), len(items), C.byref(tot)))
+    assert tot.value == begin[nq] and tot.value > 5000
+    nonempty = 0
+    for i in range(nq):
+        got = items[begin[i]:begin[i + 1]]
+        if xyr[i, 2] < 0:
+            assert len(got) == 0
+            continue
+        want = oracle.grid_query(k0, tuple(bounds), float(xyr[i, 0]), float(xyr[i, 1]), float(xyr[i, 2]), int(lv[i, 0]), int(lv[i, 1]))
+        assert np.array_equal(got & 0xffff, want.astype(np.uint32)), f"query {i}: candidate order"
+        for j in (0, len(want) // 2, len(want) - 1):
+            if len(want):
+                assert int(got[j] >> 16) == oracle.descriptor_distance(qd[i], d0[want[j]])
+        nonempty += len(want) > 0
+    assert nonempty > 300
+    # device-resident grid of a batch: bucket offsets and contents = the host grid of each frame
+    dev = torch.device("cuda", 0)
+    cap = ex.max_keypoints(640, 480)
+    d_img = torch.from_numpy(img).to(dev)
+    kps = torch.zeros((2, cap * 28), dtype=torch.uint8, device=dev); desc = torch.zeros((2, cap * 32), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev); st = torch.zeros(2, dtype=torch.int32, device=dev)
+    cb = torch.zeros((2, 64 * 48 + 1), dtype=torch.int32, device=dev); it = torch.zeros((2, cap), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    ex.extract_batch_device(d_img, 2, 640, 480, 640, 640 * 480, kps, desc, cnt, st, cap)
+    _capi.check(L.orbx_grid_build_device(ex.handle, 2, ptr(kps), ptr(cnt), cap, ptr(bounds), ptr(cb), ptr(it)))
+    ex.synchronize()
+    cbh, ith = cb.cpu().numpy(), it.cpu().numpy().view(np.uint16)
+    for f, kk in enumerate((k0, k1)):
+        px = np.floor((kk["x"] - bounds[0]) * np.float32(64.0 / 640.0) + np.float32(0.5)).astype(int)   # round(): coordinates are >= 0
+        py = np.floor((kk["y"] - bounds[2]) * np.float32(48.0 / 480.0) + np.float32(0.5)).astype(int)
+        ok = (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+        cell = px * 48 + py
+        assert cbh[f, -1] == ok.sum()
+        for c in rng.integers(0, 64 * 48, 400):
+            want = np.nonzero(ok & (cell == c))[0]
+            assert np.array_equal(ith[f, cbh[f, c]:cbh[f, c + 1]], want.astype(np.uint16)), (f, c)
