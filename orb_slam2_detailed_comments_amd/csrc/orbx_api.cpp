@@ -51,8 +51,7 @@ struct orbx_handle {
     int fast_stop = 0;      // ORBX_FAST_STOP: only read in -DORBX_TIMING_KNOBS builds
     int fast_lcap = 640;    // LDS work-list entries of k_fast_rows (ORBX_FAST_LCAP; tests shrink it to force the flush paths)
     OrbxTap *d_taps = nullptr;
-    uint2 *d_cand = nullptr, *d_dense = nullptr;   // per-cell candidate slots / dense per-level key arrays
-    int *d_cell_count = nullptr;
+    uint2 *d_dense = nullptr;   // dense per-(frame, level) key arrays, appended to by k_fast_rows (fill counts in d_cand_count)
     int *d_cand_count = nullptr, *d_lvl_count = nullptr, *d_status = nullptr;
     uint32_t *d_lvl_kp = nullptr;
     float *d_lvl_angle = nullptr;
@@ -68,6 +67,8 @@ struct orbx_handle {
     int mk_w = 0, mk_h = 0, mk_total = 0;   // orbx_max_keypoints cache
     void *d_match_ws = nullptr; size_t match_ws_bytes = 0;   // partial (best, second) keys of k_match
     uint32_t *d_gate_items = nullptr; size_t gate_items_cap = 0;   // candidate lists of k_gate / distance blocks of k_block_dist (grow-only)
+    uint8_t *pin = nullptr; size_t pin_bytes = 0;                  // page-locked staging of the host-buffer policy entry points (grow-only)
+    size_t gate_guess = 4096;                                      // entries the speculative download of the candidate lists covers
     // grow-only scratch arena for the host-buffer convenience entry points (match / matrix / stereo): no hipMalloc
     // on the steady-state path and nothing to leak on an error return
     uint8_t *d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
@@ -148,11 +149,11 @@ static void prof_drain(orbx_handle *h) {
 // ---------------------------------------------------------------- workspace
 static void free_geometry_buffers(orbx_handle *h) {
     hipFree(h->d_groups); h->d_groups = nullptr;
-    hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cells); hipFree(h->d_taps); hipFree(h->d_cand);
-    hipFree(h->d_dense); hipFree(h->d_cell_count); h->d_dense = nullptr; h->d_cell_count = nullptr;
+    hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cells); hipFree(h->d_taps);
+    hipFree(h->d_dense); h->d_dense = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_lvl_count); hipFree(h->d_status); hipFree(h->d_lvl_kp);
     hipFree(h->d_lvl_angle); hipFree(h->d_knode);
-    h->d_pyr = h->d_blur = nullptr; h->d_cells = nullptr; h->d_taps = nullptr; h->d_cand = nullptr;
+    h->d_pyr = h->d_blur = nullptr; h->d_cells = nullptr; h->d_taps = nullptr;
     h->d_cand_count = h->d_lvl_count = h->d_status = nullptr; h->d_lvl_kp = nullptr; h->d_lvl_angle = nullptr;
     h->d_knode = nullptr;
     h->configured = false;
@@ -245,9 +246,7 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
         ORBX_TRY(hipMalloc(&h->d_pyr, (size_t)B * hg.pyr_bytes + 256));   // +256: kernels read whole aligned dwords
         ORBX_TRY(hipMalloc(&h->d_cells, std::max<size_t>(1, hg.cells.size()) * sizeof(OrbxCell)));
         ORBX_TRY(hipMalloc(&h->d_taps, std::max<size_t>(1, hg.taps.size()) * sizeof(OrbxTap)));
-        ORBX_TRY(hipMalloc(&h->d_cand, (size_t)B * hg.cand_total * sizeof(uint2)));
         ORBX_TRY(hipMalloc(&h->d_dense, (size_t)B * hg.cand_total * sizeof(uint2)));
-        ORBX_TRY(hipMalloc(&h->d_cell_count, (size_t)B * std::max<size_t>(1, hg.cells.size()) * sizeof(int)));
         ORBX_TRY(hipMalloc(&h->d_knode, (size_t)B * hg.cand_total * sizeof(uint16_t)));
         ORBX_TRY(hipMalloc(&h->d_cand_count, (size_t)B * NL * sizeof(int)));
         ORBX_TRY(hipMalloc(&h->d_lvl_count, (size_t)B * NL * sizeof(int)));
@@ -333,6 +332,7 @@ extern "C" void orbx_destroy(orbx_handle *h) {
         for (auto e : h->pool) hipEventDestroy(e);
         free_geometry_buffers(h);
         hipFree(h->d_match_ws); hipFree(h->d_scratch); hipFree(h->d_rect); hipFree(h->d_gate_items);
+        if (h->pin) hipHostFree(h->pin);
         for (int s = 0; s < 2; ++s) {
             hipFree(h->st_in[s]); hipFree(h->st_kps[s]); hipFree(h->st_desc[s]); hipFree(h->st_cnt[s]);
             if (h->ev_in[s]) hipEventDestroy(h->ev_in[s]);
@@ -431,13 +431,13 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
     // event waits and the 8 small FAST launches cost more than the overlap recovers.)
     { ProfScope ps(h, ORBX_K_PYR_L0);
       if (h->d_rect) {   // cv::remap of the EuRoC rectification fused into level 0
-          orbx_launch_pyr_l0_remap(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, h->d_rect, d_status);
+          orbx_launch_pyr_l0_remap(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, h->d_rect, d_status, h->d_cand_count);
       } else if (h->input_format == ORBX_FMT_GRAY8) {
-          orbx_launch_pyr_l0(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, d_status);
+          orbx_launch_pyr_l0(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, d_status, h->d_cand_count);
       } else {   // cvtColor of Tracking::GrabImage* fused into level 0
           const int nch = (h->input_format == ORBX_FMT_RGB8 || h->input_format == ORBX_FMT_BGR8) ? 3 : 4;
           const bool rgb = h->input_format == ORBX_FMT_RGB8 || h->input_format == ORBX_FMT_RGBA8;
-          orbx_launch_pyr_l0_color(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, nch, rgb ? 0 : 2, rgb ? 2 : 0, d_status);
+          orbx_launch_pyr_l0_color(s, g, B, d_imgs, W, H, stride, frame_stride, h->d_pyr, nch, rgb ? 0 : 2, rgb ? 2 : 0, d_status, h->d_cand_count);
       } }
     // Large batches fork after level fork_level - 1: the remaining (small) levels are resized on the high-priority side stream
     // -- seven dependent launches of which the last four have few waves and are pure latency -- followed by their FAST
@@ -458,23 +458,23 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
             orbx_launch_pyr_resize(s2, g, B, l, h->d_taps, h->d_pyr, h->geom.lv[l].narrow_taps && !h->resize_legacy);
         }
         { ProfScope ps(h, ORBX_K_FAST, s2);
-          orbx_launch_fast_rows(s2, g, B, h->d_cells, h->d_groups + h->fork_group, ngroups - h->fork_group, h->d_pyr, h->d_cand,
-                                h->d_cell_count, h->max_ch, h->fast_lcap, h->fast_stop); }
+          orbx_launch_fast_rows(s2, g, B, h->d_cells, h->d_groups + h->fork_group, ngroups - h->fork_group, h->d_pyr, h->d_dense,
+                                h->d_cand_count, d_status, h->max_ch, h->fast_lcap, h->fast_stop); }
         // (The quadtree of the small levels was tried on the side stream behind its FAST groups: it needs CU residency the
         // FAST kernel of the large levels does not give up -- 201 us for 1024 workgroups that take 57 us alone -- and delays the
         // join.  It runs after the join.)
         { ProfScope ps(h, ORBX_K_FAST);
-          orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, h->fork_group, h->d_pyr, h->d_cand,
-                                h->d_cell_count, h->max_ch, h->fast_lcap, h->fast_stop); }
+          orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, h->fork_group, h->d_pyr, h->d_dense,
+                                h->d_cand_count, d_status, h->max_ch, h->fast_lcap, h->fast_stop); }
         if (hipEventRecord(h->ev_join, s2) != hipSuccess || hipStreamWaitEvent(s, h->ev_join, 0) != hipSuccess)
             return fail(ORBX_HIP_ERROR, "join event");
     } else {
         ProfScope ps(h, ORBX_K_FAST);
-        orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, ngroups, h->d_pyr, h->d_cand,
-                              h->d_cell_count, h->max_ch, h->fast_lcap, h->fast_stop);
+        orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, ngroups, h->d_pyr, h->d_dense,
+                              h->d_cand_count, d_status, h->max_ch, h->fast_lcap, h->fast_stop);
     }
     { ProfScope ps(h, ORBX_K_QUADTREE);
-      orbx_launch_quadtree(s, g, B, h->d_cells, h->d_cand, h->d_cell_count, h->d_dense, h->d_cand_count, h->d_lvl_kp,
+      orbx_launch_quadtree(s, g, B, h->d_dense, h->d_cand_count, h->d_lvl_kp,
                            h->d_lvl_count, d_status, h->d_knode,
                            h->ncap, h->lds_keys, 0, NL); }
     // orientation (IC_Angle) is computed inside k_describe from the same LDS patch the descriptor uses
@@ -781,9 +781,23 @@ extern "C" orbx_status orbx_grid_build_device(orbx_handle *h, int nframes, const
     return ORBX_OK;
 }
 
+static orbx_status pin_reserve(orbx_handle *h, size_t bytes) {
+    if (bytes <= h->pin_bytes) return ORBX_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->pin) hipHostFree(h->pin);
+    h->pin = nullptr; h->pin_bytes = 0;
+    const size_t want = std::max(bytes + bytes / 2, (size_t)1 << 20);
+    HIPCHK(hipHostMalloc((void **)&h->pin, want, hipHostMallocDefault));
+    h->pin_bytes = want;
+    return ORBX_OK;
+}
+
+// One call = one upload (everything packed into page-locked staging), two kernels (k_grid_build, k_gate) and one download that
+// is waited for: the (offset, count) spans, the fill count, and speculatively as many candidate entries as the last call
+// produced (+50 %) -- only a call that produces more than that pays a second copy.
 orbx_status orbx_gate_lists(orbx_handle *h, const orbx_keypoint *tkeys, const uint8_t *tdesc, int nt, float min_x, float max_x,
                             float min_y, float max_y, const DGateQuery *q, const uint8_t *qdesc, int nq, OrbxGateLists &out) {
-    out.begin.assign((size_t)std::max(nq, 0) + 1, 0u);
+    out.span.assign((size_t)std::max(nq, 0), make_uint2(0u, 0u));
     out.items.clear();
     if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
     if (nq <= 0 || nt <= 0) return ORBX_OK;
@@ -791,38 +805,60 @@ orbx_status orbx_gate_lists(orbx_handle *h, const orbx_keypoint *tkeys, const ui
     DGrid gp;
     if (!grid_params(min_x, max_x, min_y, max_y, gp)) return fail(ORBX_BAD_ARGUMENT, "bad image bounds");
     HIPCHK(hipSetDevice(h->dev));
-    const size_t b_keys = pad256((size_t)nt * sizeof(orbx_keypoint)), b_desc = pad256((size_t)nt * 32),
-                 b_cb = pad256((size_t)(64 * 48 + 1) * sizeof(int)), b_it = pad256((size_t)nt * sizeof(uint16_t)),
-                 b_q = pad256((size_t)nq * sizeof(DGateQuery)), b_qd = pad256((size_t)nq * 32), b_beg = pad256((size_t)(nq + 1) * 4);
-    orbx_status st = scratch_reserve(h, b_keys + b_desc + b_cb + b_it + b_q + b_qd + b_beg + 256);
+    // input block (uploaded in one copy): cursor | keys | descriptors | queries | query descriptors
+    const size_t o_cur = 0, o_keys = 256, o_desc = o_keys + pad256((size_t)nt * sizeof(orbx_keypoint)), o_q = o_desc + pad256((size_t)nt * 32),
+                 o_qd = o_q + pad256((size_t)nq * sizeof(DGateQuery)), in_bytes = o_qd + pad256((size_t)nq * 32);
+    // device-only: bucket offsets | bucket items | spans
+    const size_t o_cb = in_bytes, o_it = o_cb + pad256((size_t)(64 * 48 + 1) * sizeof(int)), o_span = o_it + pad256((size_t)nt * sizeof(uint16_t)),
+                 dev_bytes = o_span + pad256((size_t)nq * sizeof(uint2));
+    orbx_status st = scratch_reserve(h, dev_bytes + 256);
     if (st != ORBX_OK) return st;
-    orbx_keypoint *dk = scratch_take<orbx_keypoint>(h, (size_t)nt);
-    uint8_t *dd = scratch_take<uint8_t>(h, (size_t)nt * 32);
-    int *dcb = scratch_take<int>(h, 64 * 48 + 1);
-    uint16_t *dit = scratch_take<uint16_t>(h, (size_t)nt);
-    DGateQuery *dq = scratch_take<DGateQuery>(h, (size_t)nq);
-    uint8_t *dqd = scratch_take<uint8_t>(h, (size_t)nq * 32);
-    uint32_t *dbeg = scratch_take<uint32_t>(h, (size_t)nq + 1);
+    st = gate_items_reserve(h, std::max(h->gate_guess, (size_t)1 << 16));
+    if (st != ORBX_OK) return st;
+    const size_t span_bytes = (size_t)nq * sizeof(uint2);
+    size_t guess = std::min(h->gate_guess, h->gate_items_cap);
+    st = pin_reserve(h, in_bytes + span_bytes + 256 + h->gate_items_cap * 4);
+    if (st != ORBX_OK) return st;
+    uint8_t *pin_in = h->pin, *pin_out = h->pin + in_bytes;   // pin_out: spans | cursor (256) | items
+    memset(pin_in + o_cur, 0, 256);
+    memcpy(pin_in + o_keys, tkeys, (size_t)nt * sizeof(orbx_keypoint));
+    memcpy(pin_in + o_desc, tdesc, (size_t)nt * 32);
+    memcpy(pin_in + o_q, q, (size_t)nq * sizeof(DGateQuery));
+    memcpy(pin_in + o_qd, qdesc, (size_t)nq * 32);
+    uint8_t *d = scratch_take<uint8_t>(h, dev_bytes);
+    uint32_t *dcur = (uint32_t *)(d + o_cur);
+    const orbx_keypoint *dk = (const orbx_keypoint *)(d + o_keys);
     hipStream_t s = h->stream;
-    HIPCHK(hipMemcpyAsync(dk, tkeys, (size_t)nt * sizeof(orbx_keypoint), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(dd, tdesc, (size_t)nt * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * sizeof(DGateQuery), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(dqd, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, s));
-    { ProfScope ps(h, ORBX_K_MATCH);
-      orbx_launch_grid_build(s, gp, 1, dk, nullptr, nt, nt, dcb, dit);
-      orbx_launch_gate(s, gp, dk, dd, dcb, dit, dq, dqd, nq, dbeg, nullptr, false);   // pass 1: candidates per query
-      orbx_launch_scan_u32(s, dbeg, nq); }
-    HIPCHK(hipMemcpyAsync(out.begin.data(), dbeg, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const size_t total = out.begin[(size_t)nq];
-    if (total == 0) return ORBX_OK;
-    st = gate_items_reserve(h, total);
-    if (st != ORBX_OK) return st;
-    { ProfScope ps(h, ORBX_K_MATCH);
-      orbx_launch_gate(s, gp, dk, dd, dcb, dit, dq, dqd, nq, dbeg, h->d_gate_items, true); }   // pass 2: ordered (index, distance) lists
+    HIPCHK(hipMemcpyAsync(d, pin_in, in_bytes, hipMemcpyHostToDevice, s));
+    uint32_t total = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        { ProfScope ps(h, ORBX_K_MATCH);
+          if (attempt == 0) orbx_launch_grid_build(s, gp, 1, dk, nullptr, nt, nt, (int *)(d + o_cb), (uint16_t *)(d + o_it));
+          orbx_launch_gate(s, gp, dk, d + o_desc, (const int *)(d + o_cb), (const uint16_t *)(d + o_it), (const DGateQuery *)(d + o_q),
+                           d + o_qd, nq, (uint2 *)(d + o_span), dcur, h->d_gate_items, (uint32_t)std::min<size_t>(h->gate_items_cap, 0xffffffffu)); }
+        HIPCHK(hipMemcpyAsync(pin_out, d + o_span, span_bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(pin_out + span_bytes, dcur, 4, hipMemcpyDeviceToHost, s));
+        if (guess > 0) HIPCHK(hipMemcpyAsync(pin_out + span_bytes + 256, h->d_gate_items, guess * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        memcpy(&total, pin_out + span_bytes, 4);
+        if (total <= h->gate_items_cap) break;
+        // the lists did not fit the buffer: nothing beyond the spans was trusted; grow, reset the cursor, run k_gate again
+        if (attempt == 1) return fail(ORBX_CAPACITY, "candidate lists");
+        st = gate_items_reserve(h, total);
+        if (st == ORBX_OK) st = pin_reserve(h, in_bytes + span_bytes + 256 + h->gate_items_cap * 4);
+        if (st != ORBX_OK) return st;
+        pin_in = h->pin; pin_out = h->pin + in_bytes;
+        HIPCHK(hipMemsetAsync(dcur, 0, 4, s));
+        guess = total;
+    }
+    if (total > guess) {   // more entries than the speculative copy covered
+        HIPCHK(hipMemcpyAsync(pin_out + span_bytes + 256 + guess * 4, h->d_gate_items + guess, (size_t)(total - guess) * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    h->gate_guess = std::max<size_t>(4096, (size_t)total + total / 2);
+    memcpy(out.span.data(), pin_out, span_bytes);
     out.items.resize(total);
-    HIPCHK(hipMemcpyAsync(out.items.data(), h->d_gate_items, total * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    if (total) memcpy(out.items.data(), pin_out + span_bytes + 256, (size_t)total * 4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
     return ORBX_OK;
@@ -839,10 +875,12 @@ extern "C" orbx_status orbx_gated_candidates(orbx_handle *h, const orbx_keypoint
     OrbxGateLists L;
     orbx_status st = orbx_gate_lists(h, tkeys, tdesc, nt, bounds4[0], bounds4[1], bounds4[2], bounds4[3], q.data(), qdesc, nq, L);
     if (st != ORBX_OK) return st;
-    memcpy(begin, L.begin.data(), ((size_t)nq + 1) * 4);
-    *total = (int)L.items.size();
-    if ((int)L.items.size() > items_cap) return fail(ORBX_CAPACITY, "candidate list capacity");
-    if (!L.items.empty() && items) memcpy(items, L.items.data(), L.items.size() * 4);
+    begin[0] = 0;
+    for (int i = 0; i < nq; ++i) begin[i + 1] = begin[i] + (uint32_t)L.count(i);
+    *total = (int)begin[nq];
+    if ((int)begin[nq] > items_cap) return fail(ORBX_CAPACITY, "candidate list capacity");
+    for (int i = 0; i < nq && items; ++i)
+        if (L.count(i)) memcpy(items + begin[i], L.list(i), (size_t)L.count(i) * 4);
     return ORBX_OK;
 }
 
@@ -853,23 +891,26 @@ orbx_status orbx_block_distances(orbx_handle *h, const uint8_t *d1, int n1, cons
     if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
     if (rows.empty() || total == 0) return ORBX_OK;
     HIPCHK(hipSetDevice(h->dev));
-    orbx_status st = scratch_reserve(h, pad256((size_t)n1 * 32) + pad256((size_t)n2 * 32) + pad256(rows.size() * sizeof(DDistRow)) +
-                                            pad256(col_idx.size() * 4) + 256);
+    const size_t o_a = 0, o_b = o_a + pad256((size_t)n1 * 32), o_r = o_b + pad256((size_t)n2 * 32),
+                 o_c = o_r + pad256(rows.size() * sizeof(DDistRow)), in_bytes = o_c + pad256(col_idx.size() * 4);
+    orbx_status st = scratch_reserve(h, in_bytes + 256);
+    if (st == ORBX_OK) st = gate_items_reserve(h, (total + 1) / 2);
+    if (st == ORBX_OK) st = pin_reserve(h, in_bytes + pad256(total * sizeof(uint16_t)));
     if (st != ORBX_OK) return st;
-    st = gate_items_reserve(h, (total + 1) / 2);
-    if (st != ORBX_OK) return st;
-    uint8_t *a = scratch_take<uint8_t>(h, (size_t)n1 * 32), *b = scratch_take<uint8_t>(h, (size_t)n2 * 32);
-    DDistRow *dr = scratch_take<DDistRow>(h, rows.size());
-    uint32_t *dc = scratch_take<uint32_t>(h, col_idx.size());
+    uint8_t *pin_in = h->pin, *pin_out = h->pin + in_bytes;
+    memcpy(pin_in + o_a, d1, (size_t)n1 * 32);
+    memcpy(pin_in + o_b, d2, (size_t)n2 * 32);
+    memcpy(pin_in + o_r, rows.data(), rows.size() * sizeof(DDistRow));
+    memcpy(pin_in + o_c, col_idx.data(), col_idx.size() * 4);
+    uint8_t *d = scratch_take<uint8_t>(h, in_bytes);
     hipStream_t s = h->stream;
-    HIPCHK(hipMemcpyAsync(a, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(b, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(dr, rows.data(), rows.size() * sizeof(DDistRow), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(dc, col_idx.data(), col_idx.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d, pin_in, in_bytes, hipMemcpyHostToDevice, s));
     { ProfScope ps(h, ORBX_K_MATCH);
-      orbx_launch_block_dist(s, a, b, dr, dc, (int)rows.size(), (uint16_t *)h->d_gate_items); }
-    HIPCHK(hipMemcpyAsync(out.data(), h->d_gate_items, total * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+      orbx_launch_block_dist(s, d + o_a, d + o_b, (const DDistRow *)(d + o_r), (const uint32_t *)(d + o_c), (int)rows.size(),
+                             (uint16_t *)h->d_gate_items); }
+    HIPCHK(hipMemcpyAsync(pin_out, h->d_gate_items, total * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    memcpy(out.data(), pin_out, total * sizeof(uint16_t));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
     return ORBX_OK;

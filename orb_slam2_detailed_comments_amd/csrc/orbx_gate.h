@@ -11,10 +11,10 @@
 #include "orbx_device.h"
 
 struct OrbxGateLists {
-    std::vector<uint32_t> begin;   // nq + 1 offsets into items
+    std::vector<uint2> span;       // per query: (offset into items, count) -- queries are stored in the order their waves reserved
     std::vector<uint32_t> items;   // idx | dist << 16
-    int count(int q) const { return (int)(begin[(size_t)q + 1] - begin[(size_t)q]); }
-    const uint32_t *list(int q) const { return items.data() + begin[(size_t)q]; }
+    int count(int q) const { return (int)span[(size_t)q].y; }
+    const uint32_t *list(int q) const { return items.data() + span[(size_t)q].x; }
     static int idx(uint32_t v) { return (int)(v & 0xffffu); }
     static int dist(uint32_t v) { return (int)(v >> 16); }
 };

@@ -28,7 +28,7 @@
 #endif
 __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restrict__ imgs, int W, int H, int stride,
                                                 long long frame_stride, uint8_t *__restrict__ pyr, int xe,
-                                                int *__restrict__ status) {
+                                                int *__restrict__ status, int *__restrict__ cand_cursor) {
     // block = 64 x 4 threads, thread = L0_ROWS rows.  Blocks with blockIdx.x < gridDim.x - 1 copy the interior
     // columns [32, xe) with dword-aligned loads + funnel shifts (16 pixels per thread and row); the LAST block column
     // owns the two border strips [0, 32) and [xe, pitch) where reflect-101 reverses the byte order (byte gathers).
@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restri
 #endif
     // the per-frame status word (atomicMax'ed by the later kernels of the batch) is reset here: level 0 is the first kernel of
     // every batch, which saves a separate clearing launch in front of it
-    if (bx == 0 && by == 0 && threadIdx.x == 0 && threadIdx.y == 0) status[f] = 0;
+    if (bx == 0 && by == 0 && threadIdx.y == 0) {
+        if (threadIdx.x == 0) status[f] = 0;
+        if ((int)threadIdx.x < g.nlevels) cand_cursor[f * g.nlevels + threadIdx.x] = 0;   // appended to by k_fast_rows
+    }
     const int Y0 = (by * 4 + threadIdx.y) * L0_ROWS;
     if (Y0 >= L.ph) return;
     const uint8_t *img = imgs + (long long)f * frame_stride;
@@ -90,12 +93,15 @@ __global__ __launch_bounds__(256) void k_pyr_l0(DGeom g, const uint8_t *__restri
 // OpenCV 3.2 8-bit formula: gray = (R*4899 + G*9617 + B*1868 + 8192) >> 14.  thread = 4 padded pixels.
 __global__ __launch_bounds__(256) void k_pyr_l0_color(DGeom g, const uint8_t *__restrict__ imgs, int W, int H, int stride,
                                                       long long frame_stride, uint8_t *__restrict__ pyr, int nch,
-                                                      int r_off, int b_off, int *__restrict__ status) {
+                                                      int r_off, int b_off, int *__restrict__ status, int *__restrict__ cand_cursor) {
     const DLevel &L = g.lv[0];
     const int X = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int Y = blockIdx.y * 4 + threadIdx.y;
     const int f = blockIdx.z;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) status[f] = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.y == 0) {
+        if (threadIdx.x == 0) status[f] = 0;
+        if ((int)threadIdx.x < g.nlevels) cand_cursor[f * g.nlevels + threadIdx.x] = 0;
+    }
     if (X >= L.pw || Y >= L.ph) return;
     const uint8_t *src = imgs + (long long)f * frame_stride + (long long)orbx_reflect101(Y - ORBX_EDGE, H) * stride;
     uint32_t v = 0;
@@ -120,12 +126,16 @@ __global__ __launch_bounds__(256) void k_pyr_l0_color(DGeom g, const uint8_t *__
 // rect entry: .x = ix | iy << 16 (int16 each), .y = fy << 5 | fx.  thread = 4 padded pixels.
 __global__ __launch_bounds__(256) void k_pyr_l0_remap(DGeom g, const uint8_t *__restrict__ imgs, int W, int H, int stride,
                                                       long long frame_stride, uint8_t *__restrict__ pyr,
-                                                      const uint2 *__restrict__ rect, int *__restrict__ status) {
+                                                      const uint2 *__restrict__ rect, int *__restrict__ status,
+                                                      int *__restrict__ cand_cursor) {
     const DLevel &L = g.lv[0];
     const int X = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int Y = blockIdx.y * 4 + threadIdx.y;
     const int f = blockIdx.z;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) status[f] = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.y == 0) {
+        if (threadIdx.x == 0) status[f] = 0;
+        if ((int)threadIdx.x < g.nlevels) cand_cursor[f * g.nlevels + threadIdx.x] = 0;
+    }
     if (X >= L.pw || Y >= L.ph) return;
     const uint8_t *src = imgs + (long long)f * frame_stride;
     const uint2 *mrow = rect + (long long)orbx_reflect101(Y - ORBX_EDGE, H) * W;
@@ -487,8 +497,10 @@ struct FrCells {
     int iw0;                        // interior columns of the first cell (64 when the group is a single cell)
     int offx0, offx1, offy;         // j*wCell of the two cells, i*hCell
     int ord0, ord1;                 // idx_in_level
-    int cap0, cap1;                 // slot_cap
-    uint2 *out0, *out1;             // slot ranges
+    int cap0, cap1;                 // slot_cap: survivors a cell may report (exact NMS worst case unless max_cand_per_cell cut it)
+    uint2 *out;                     // dense candidate array of this (frame, level)
+    int *cursor;                    // its fill count: one returning atomicAdd per NMS round reserves the round's survivors
+    int out_cap;                    // entries the array holds
 };
 __device__ __forceinline__ void fr_nms(const FrCtx &c, const FrCells &gc, const uint16_t *list, int n, int &ns0, int &ns1) {
     for (int e0 = 0; e0 < n; e0 += 64) {
@@ -510,13 +522,23 @@ __device__ __forceinline__ void fr_nms(const FrCtx &c, const FrCells &gc, const 
                           (int)(sc > r2) & (int)(sc > u) & (int)(sc > dn);
         const unsigned long long m = orbx_ballot(keep), msec = orbx_ballot(keep && second);
         const unsigned long long mfirst = m & ~msec;
-        const int slot = second ? ns1 + orbx_wave_rank(msec) : ns0 + orbx_wave_rank(mfirst);
-        if (keep && slot < (second ? gc.cap1 : gc.cap0)) {
-            const int lx = 3 + col - (second ? gc.iw0 : 0);
-            uint2 o;
-            o.x = (uint32_t)(lx + (second ? gc.offx1 : gc.offx0)) | ((uint32_t)(ly + gc.offy) << 12) | ((uint32_t)sc << 24);
-            o.y = ((uint32_t)(second ? gc.ord1 : gc.ord0) << 12) | ((uint32_t)ly << 6) | (uint32_t)lx;   // emission order key
-            (second ? gc.out1 : gc.out0)[slot] = o;
+        const int slot = second ? ns1 + orbx_wave_rank(msec) : ns0 + orbx_wave_rank(mfirst);   // ordinal inside the cell
+        const bool ok = keep && slot < (second ? gc.cap1 : gc.cap0);
+        const unsigned long long mok = orbx_ballot(ok);
+        if (mok != 0ull) {
+            // The survivors go straight into the level's dense key array (any order: every record carries its emission-order
+            // key, and the quadtree is order-free): no per-cell slot ranges, no gather pass in front of the quadtree.
+            int base = 0;
+            if (c.lane == 0) base = atomicAdd(gc.cursor, (int)__popcll(mok));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int pos = base + orbx_wave_rank(mok);
+            if (ok && pos < gc.out_cap) {
+                const int lx = 3 + col - (second ? gc.iw0 : 0);
+                uint2 o;
+                o.x = (uint32_t)(lx + (second ? gc.offx1 : gc.offx0)) | ((uint32_t)(ly + gc.offy) << 12) | ((uint32_t)sc << 24);
+                o.y = ((uint32_t)(second ? gc.ord1 : gc.ord0) << 12) | ((uint32_t)ly << 6) | (uint32_t)lx;   // emission order key
+                gc.out[pos] = o;
+            }
         }
         ns0 += __popcll(mfirst);
         ns1 += __popcll(msec);
@@ -526,8 +548,8 @@ __device__ __forceinline__ void fr_nms(const FrCtx &c, const FrCells &gc, const 
 __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCell *__restrict__ cells,
                                                           const OrbxFastGroup *__restrict__ groups,
                                                           const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
-                                                          int *__restrict__ cell_count, int rows, int lcap, int ngroups,
-                                                          int gpw, int dbg_stop) {
+                                                          int *__restrict__ cand_cursor, int *__restrict__ status, int rows,
+                                                          int lcap, int ngroups, int gpw, int dbg_stop) {
     // dbg_stop (ORBX_FAST_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS; results are wrong unless 0): 1 = after
     // staging, 2 = after the pre-test, 3 = after the ring test, 4 = before NMS.  The shipped library pins it to 0.
 #ifndef ORBX_TIMING_KNOBS
@@ -619,8 +641,9 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     gc.offx0 = c0.offx; gc.offx1 = c1.offx; gc.offy = c0.offy;
     gc.ord0 = c0.idx_in_level; gc.ord1 = c1.idx_in_level;
     gc.cap0 = c0.slot_cap; gc.cap1 = c1.slot_cap;
-    uint2 *lvl_out = cand + (long long)f * g.cand_total + L.cand_begin;
-    gc.out0 = lvl_out + c0.slot_begin; gc.out1 = lvl_out + c1.slot_begin;
+    gc.out = cand + (long long)f * g.cand_total + L.cand_begin;
+    gc.cursor = cand_cursor + f * g.nlevels + c0.level;
+    gc.out_cap = L.cand_cap;
     orbx_wave_sync();
     if (dbg_stop == 1) continue;
     const bool two_th = g.min_th != g.ini_th;
@@ -692,7 +715,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
 #undef FR_STEP
             const int n = (int)((nb - list0) >> 1);
             orbx_wave_sync();
-            if (dbg_stop == 2) { if (n == 12345) cell_count[0] = n; continue; }
+            if (dbg_stop == 2) { if (n == 12345) cand_cursor[0] = n; continue; }
             const int ncorn = fr_ring_and_score(cx, n, th, dbg_stop);
             // keep the corners for the NMS walk while they fit
             if (!overflow && nctot + ncorn <= lcap) {
@@ -734,11 +757,8 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         for (int i = lane; i < (th_rows * (FR_TP / 4) + 3) / 4; i += 64) ((uint4 *)s_score)[i] = make_uint4(0, 0, 0, 0);
         orbx_wave_sync();
     }
-    if (lane == 0) {
-        int *cc = cell_count + (long long)f * g.ncells + grp.cell0;
-        cc[0] = ns0;
-        if (grp.ncell == 2) cc[1] = ns1;
-    }
+    // more survivors than the cell may report (only when max_cand_per_cell cut the exact worst case): reported, not silent
+    if (lane == 0 && (ns0 > gc.cap0 || (grp.ncell == 2 && ns1 > gc.cap1))) atomicMax(&status[f], (int)ORBX_CAPACITY);
     orbx_wave_sync();   // the next group overwrites tile / score / lists
   }
 #undef FR_PREFETCH
@@ -810,10 +830,8 @@ __device__ __forceinline__ void qt_child_box(uint32_t b0, uint32_t b1, int q, ui
     c1 = (uint32_t)cx1 | ((uint32_t)cy1 << 16);
 }
 
-__global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell *__restrict__ cells,
-                                                        const uint2 *__restrict__ slots_all,
-                                                        const int *__restrict__ cell_count, uint2 *__restrict__ dense_all,
-                                                        int *__restrict__ cand_count,
+__global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *__restrict__ dense_all,
+                                                        const int *__restrict__ cand_count,
                                                         uint32_t *__restrict__ lvl_kp, int *__restrict__ lvl_count,
                                                         int *__restrict__ status, uint16_t *__restrict__ knode_glob,
                                                         int ncap, int lds_keys, int level_begin) {
@@ -827,12 +845,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
 #endif
     const DLevel &L = g.lv[level];
     const int N = L.nfeat;
-    const uint2 *slots = slots_all + (long long)f * g.cand_total + L.cand_begin;
-    uint2 *cand = dense_all + (long long)f * g.cand_total + L.cand_begin;
+    const uint2 *cand = dense_all + (long long)f * g.cand_total + L.cand_begin;
     // ---- LDS carve-up (all arrays have ncap entries unless noted)
     uint8_t *sp = qt_smem;
     QtShared *sh = (QtShared *)sp;                 sp += 128;
-    uint32_t *cscan = (uint32_t *)sp;              sp += 4 * QT_THREADS;      // per-thread cell-chunk totals / offsets
+    sp += 4 * QT_THREADS;   // (reserved: keeps orbx_quadtree_smem's layout)
     unsigned long long *best = (unsigned long long *)sp; sp += 8 * (size_t)ncap;
     uint32_t *boxA0 = (uint32_t *)sp;              sp += 4 * (size_t)ncap;
     uint32_t *boxA1 = (uint32_t *)sp;              sp += 4 * (size_t)ncap;
@@ -855,56 +872,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const OrbxCell
     uint32_t *box0 = boxA0, *box1 = boxA1, *cnt = cntA, *meta = metaA;
     uint32_t *nbox0 = boxB0, *nbox1 = boxB1, *ncnt = cntB, *nmeta = metaB;
 
-    // ---- gather: the FAST kernel left every cell's survivors in the cell's own slot range; pack them into a
-    // dense key array (cell order, so the result is independent of scheduling).  thread = a chunk of cells.
-    const int nc = L.cell_count;
-    const int chunk = (nc + QT_THREADS - 1) / QT_THREADS;
-    const int c_begin = min(tid * chunk, nc), c_end = min(c_begin + chunk, nc);
-    // The first cell of a thread (the only one at the usual one cell per thread) keeps its record, count and first four
-    // slots in registers across the scan: the slot loads are issued BEFORE the scan, so the chain is
-    // {count, cell record} -> slots (under the scan) -> stores instead of count -> scan -> cell record -> slots -> stores.
-    OrbxCell cl0 = {};
-    int cnt0 = 0;
-    uint2 p0 = make_uint2(0, 0), p1 = p0, p2 = p0, p3 = p0;
-    {
-        uint32_t mine = 0;
-        for (int i = c_begin; i < c_end; ++i) {
-            const OrbxCell cl = cells[L.cell_begin + i];
-            int c = cell_count[(long long)f * g.ncells + L.cell_begin + i];
-            if (c > cl.slot_cap) { atomicMax(&status[f], (int)ORBX_CAPACITY); c = cl.slot_cap; }
-            mine += (uint32_t)c;
-            if (i == c_begin) {
-                cl0 = cl; cnt0 = c;
-                const uint2 *src = slots + cl.slot_begin;   // (slot ranges are always mapped)
-                p0 = src[0]; p1 = src[min(1, cl.slot_cap - 1)]; p2 = src[min(2, cl.slot_cap - 1)]; p3 = src[min(3, cl.slot_cap - 1)];
-            }
-        }
-        cscan[tid] = mine;
-    }
-    __syncthreads();
-    const int K = (int)qt_block_scan(cscan, cscan, QT_THREADS, sh);
+    // ---- keys: k_fast_rows appended this level's survivors to the dense array (count in cand_count); nothing to gather
+    const int K = min(cand_count[f * g.nlevels + level], L.cand_cap);
     const bool keys_in_lds = K <= lds_keys;   // wave-uniform: key positions and key->node map live in LDS
-    {
-        uint32_t o = cscan[tid];
-        for (int i = c_begin; i < c_end; ++i) {
-            OrbxCell cl; int c; uint2 e0, e1, e2, e3;
-            if (i == c_begin) { cl = cl0; c = cnt0; e0 = p0; e1 = p1; e2 = p2; e3 = p3; }
-            else {
-                cl = cells[L.cell_begin + i];
-                c = min(cell_count[(long long)f * g.ncells + L.cell_begin + i], cl.slot_cap);
-                const uint2 *srcn = slots + cl.slot_begin;
-                e0 = srcn[0]; e1 = srcn[min(1, cl.slot_cap - 1)]; e2 = srcn[min(2, cl.slot_cap - 1)]; e3 = srcn[min(3, cl.slot_cap - 1)];
-            }
-            const uint2 *src = slots + cl.slot_begin;
-            for (int e = 0; e < c; ++e) {
-                const uint2 v = e == 0 ? e0 : e == 1 ? e1 : e == 2 ? e2 : e == 3 ? e3 : src[e];
-                cand[o + e] = v;
-                if (keys_in_lds) kpos_lds[o + e] = v.x;
-            }
-            o += (uint32_t)c;
-        }
-    }
-    if (tid == 0) cand_count[f * g.nlevels + level] = K;
+    if (keys_in_lds)
+        for (int k = tid; k < K; k += QT_THREADS) kpos_lds[k] = cand[k].x;
     uint16_t *knode = keys_in_lds ? knode_lds : knode_glob + ((long long)f * g.cand_total + L.cand_begin);
 #define QT_KPOS(k) (keys_in_lds ? kpos_lds[k] : cand[k].x)
     __syncthreads();
@@ -1966,76 +1938,69 @@ __global__ __launch_bounds__(1024) void k_grid_build(DGrid gp, const orbx_keypoi
     }
 }
 
-// one wave per query; FILL = false: count the candidates, FILL = true: write them at out_begin[query]
-template <bool FILL>
+// One wave per query, two walks over the query's buckets: the first counts the candidates (radius / level tests only), lane 0
+// then reserves that many entries of the output with one returning atomicAdd on `cursor` and records (offset, count) in
+// span[query]; the second walk evaluates the Hamming distances and writes the entries in visiting order.  A reservation that
+// does not fit `cap` writes nothing: the host reads the total from the cursor, grows the buffer and launches again.
+__device__ __forceinline__ bool gr_pass(const DGateQuery &Q, bool check, const orbx_keypoint &kp) {
+    bool pass = fabsf(kp.x - Q.x) < Q.r && fabsf(kp.y - Q.y) < Q.r;
+    if (check) pass = pass && !(kp.octave < Q.min_level) && !(Q.max_level >= 0 && kp.octave > Q.max_level);
+    return pass;
+}
 __global__ __launch_bounds__(256) void k_gate(DGrid gp, const orbx_keypoint *__restrict__ kps, const uint8_t *__restrict__ desc,
                                               const int *__restrict__ cell_begin, const uint16_t *__restrict__ items,
                                               const DGateQuery *__restrict__ q, const uint8_t *__restrict__ qdesc, int nq,
-                                              uint32_t *__restrict__ out_begin, uint32_t *__restrict__ out_items) {
+                                              uint2 *__restrict__ span, uint32_t *__restrict__ cursor,
+                                              uint32_t *__restrict__ out_items, uint32_t cap) {
     const int lane = threadIdx.x & 63;
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (qi >= nq) return;
     const DGateQuery Q = q[qi];
-    int n = 0;
-    uint32_t base = 0;
-    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
-    if (FILL) {
-        base = out_begin[qi];
-        const uint4 *qp = (const uint4 *)(qdesc + (long long)qi * 32);
-        qa = qp[0]; qb = qp[1];
-    }
     // GetFeaturesInArea's cell range (:643-668); a negative radius switches the query off
     const int x0 = max(0, (int)floorf((Q.x - gp.minx - Q.r) * gp.winv));
     const int x1 = min(GR_COLS - 1, (int)ceilf((Q.x - gp.minx + Q.r) * gp.winv));
     const int y0 = max(0, (int)floorf((Q.y - gp.miny - Q.r) * gp.hinv));
     const int y1 = min(GR_ROWS - 1, (int)ceilf((Q.y - gp.miny + Q.r) * gp.hinv));
-    if (Q.r >= 0.f && x0 < GR_COLS && x1 >= 0 && y0 < GR_ROWS && y1 >= 0) {
-        const bool check = (Q.min_level > 0) || (Q.max_level >= 0);
+    const bool live = Q.r >= 0.f && x0 < GR_COLS && x1 >= 0 && y0 < GR_ROWS && y1 >= 0;
+    const bool check = (Q.min_level > 0) || (Q.max_level >= 0);
+    int n = 0;
+    if (live)
         for (int ix = x0; ix <= x1; ++ix) {
             const int b = cell_begin[ix * GR_ROWS + y0], e = cell_begin[ix * GR_ROWS + y1 + 1];
             for (int j0 = b; j0 < e; j0 += 64) {
                 const int j = j0 + lane;
-                bool pass = false;
-                int i2 = 0;
-                if (j < e) {
-                    i2 = items[j];
-                    const orbx_keypoint kp = kps[i2];
-                    pass = fabsf(kp.x - Q.x) < Q.r && fabsf(kp.y - Q.y) < Q.r;
-                    if (check) pass = pass && !(kp.octave < Q.min_level) && !(Q.max_level >= 0 && kp.octave > Q.max_level);
-                }
-                const unsigned long long m = orbx_ballot(pass);
-                if (FILL && pass) {
-                    const uint4 *tp = (const uint4 *)(desc + (long long)i2 * 32);
-                    const uint4 ta = tp[0], tb = tp[1];
-                    const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
-                                       __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
-                    out_items[base + (uint32_t)n + (uint32_t)orbx_wave_rank(m)] = (uint32_t)i2 | (d << 16);
-                }
-                n += __popcll(m);
+                const bool pass = j < e && gr_pass(Q, check, kps[items[j]]);
+                n += __popcll(orbx_ballot(pass));
             }
         }
+    uint32_t base = 0;
+    if (lane == 0) {
+        base = n > 0 ? atomicAdd(cursor, (uint32_t)n) : 0u;
+        span[qi] = make_uint2(base, (uint32_t)n);
     }
-    if (!FILL && lane == 0) out_begin[qi] = (uint32_t)n;
-}
-
-// exclusive prefix sum of a[0..n) in place, a[n] = total; one workgroup
-__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, int n) {
-    __shared__ uint32_t s_part[1024];
-    const int t = threadIdx.x;
-    const int chunk = (n + 1023) / 1024, b = min(t * chunk, n), e = min(b + chunk, n);
-    uint32_t sum = 0;
-    for (int i = b; i < e; ++i) sum += a[i];
-    s_part[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const uint32_t v = t >= o ? s_part[t - o] : 0u;
-        __syncthreads();
-        s_part[t] += v;
-        __syncthreads();
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (n == 0 || base + (uint32_t)n > cap) return;
+    const uint4 *qp = (const uint4 *)(qdesc + (long long)qi * 32);
+    const uint4 qa = qp[0], qb = qp[1];
+    uint32_t w = base;
+    for (int ix = x0; ix <= x1; ++ix) {
+        const int b = cell_begin[ix * GR_ROWS + y0], e = cell_begin[ix * GR_ROWS + y1 + 1];
+        for (int j0 = b; j0 < e; j0 += 64) {
+            const int j = j0 + lane;
+            bool pass = false;
+            int i2 = 0;
+            if (j < e) { i2 = items[j]; pass = gr_pass(Q, check, kps[i2]); }
+            const unsigned long long m = orbx_ballot(pass);
+            if (pass) {
+                const uint4 *tp = (const uint4 *)(desc + (long long)i2 * 32);
+                const uint4 ta = tp[0], tb = tp[1];
+                const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                                   __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+                out_items[w + (uint32_t)orbx_wave_rank(m)] = (uint32_t)i2 | (d << 16);
+            }
+            w += (uint32_t)__popcll(m);
+        }
     }
-    uint32_t run = s_part[t] - sum;
-    for (int i = b; i < e; ++i) { const uint32_t c = a[i]; a[i] = run; run += c; }
-    if (t == 1023) a[n] = s_part[1023];
 }
 
 // Hamming distances of the BoW-guided policies: row r pairs descriptor rows[r].q of the first set with the features
@@ -2112,7 +2077,7 @@ void orbx_launch_clear(hipStream_t s, int *a, int na, int *b, int nb, int *c, in
     hipLaunchKernelGGL(k_clear, dim3((n + 255) / 256), dim3(256), 0, s, a, na, b, nb, c, nc);
 }
 void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
-                        long long frame_stride, uint8_t *pyr, int *status) {
+                        long long frame_stride, uint8_t *pyr, int *status, int *cand_cursor) {
     const DLevel &L = g.lv[0];
     // interior columns [32, xe): the 20-byte aligned window of every 16-pixel chunk stays inside the source row
     int xe = 32;
@@ -2123,19 +2088,19 @@ void orbx_launch_pyr_l0(hipStream_t s, const DGeom &g, int B, const uint8_t *img
 #else
     dim3 grid(icols + 1, (L.ph + 4 * L0_ROWS - 1) / (4 * L0_ROWS), B);
 #endif
-    hipLaunchKernelGGL(k_pyr_l0, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, xe, status);
+    hipLaunchKernelGGL(k_pyr_l0, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, xe, status, cand_cursor);
 }
 void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
-                              long long frame_stride, uint8_t *pyr, int nch, int r_off, int b_off, int *status) {
+                              long long frame_stride, uint8_t *pyr, int nch, int r_off, int b_off, int *status, int *cand_cursor) {
     const DLevel &L = g.lv[0];
     dim3 grid((L.pw + 255) / 256, (L.ph + 3) / 4, B);
-    hipLaunchKernelGGL(k_pyr_l0_color, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, nch, r_off, b_off, status);
+    hipLaunchKernelGGL(k_pyr_l0_color, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, nch, r_off, b_off, status, cand_cursor);
 }
 void orbx_launch_pyr_l0_remap(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
-                              long long frame_stride, uint8_t *pyr, const uint2 *rect, int *status) {
+                              long long frame_stride, uint8_t *pyr, const uint2 *rect, int *status, int *cand_cursor) {
     const DLevel &L = g.lv[0];
     dim3 grid((L.pw + 255) / 256, (L.ph + 3) / 4, B);
-    hipLaunchKernelGGL(k_pyr_l0_remap, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, rect, status);
+    hipLaunchKernelGGL(k_pyr_l0_remap, grid, dim3(64, 4), 0, s, g, imgs, W, H, stride, frame_stride, pyr, rect, status, cand_cursor);
 }
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr, bool narrow) {
     const DLevel &L = g.lv[level];
@@ -2156,7 +2121,8 @@ void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, con
     hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, g, level, taps, pyr);
 }
 void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *groups,
-                           int ngroups, const uint8_t *pyr, uint2 *cand, int *cell_count, int max_ch, int lcap, int dbg_stop) {
+                           int ngroups, const uint8_t *pyr, uint2 *cand, int *cand_cursor, int *status, int max_ch, int lcap,
+                           int dbg_stop) {
     if (ngroups <= 0) return;
     lcap = (max(lcap, 64) + 1) & ~1;
     max_ch = (max_ch + 3) & ~3;   // tile and score map sizes multiples of 16 bytes
@@ -2165,7 +2131,7 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
     // is processed); one per wave for small batches, where the serial length of a wave is what the caller waits for
     const int gpw = (long long)B * ngroups >= 16384 ? FR_GPW : 1;
     hipLaunchKernelGGL(k_fast_rows, dim3(B, (ngroups + gpw - 1) / gpw), dim3(64), smem, s, g, cells, groups, pyr, cand,
-                       cell_count, max_ch, lcap, ngroups, gpw, dbg_stop);
+                       cand_cursor, status, max_ch, lcap, ngroups, gpw, dbg_stop);
 }
 void orbx_launch_undistort(hipStream_t s, int B, int max_n, int cap, const double *K4, const double *k14, int identity,
                            const orbx_keypoint *kps, const int *counts, orbx_keypoint *out) {
@@ -2185,12 +2151,11 @@ void orbx_launch_bow_transform(hipStream_t s, int B, int max_n, const int *child
     hipLaunchKernelGGL(k_bow_transform, dim3((max_n + 15) / 16, B), dim3(256), 0, s, v, desc, counts, frame_stride, levelsup,
                        out_leaf, out_nid, out_stride);
 }
-void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const uint2 *slots,
-                          const int *cell_count, uint2 *dense, int *cand_count, uint32_t *lvl_kp, int *lvl_count,
+void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const uint2 *dense, const int *cand_count, uint32_t *lvl_kp, int *lvl_count,
                           int *status, uint16_t *knode_glob, int ncap, int lds_keys, int level_begin, int level_count) {
     if (level_count <= 0) return;
     const size_t smem = orbx_quadtree_smem(ncap, lds_keys);
-    hipLaunchKernelGGL(k_quadtree, QT_FF ? dim3(B, level_count) : dim3(level_count, B), dim3(QT_THREADS), smem, s, g, cells, slots, cell_count, dense,
+    hipLaunchKernelGGL(k_quadtree, QT_FF ? dim3(B, level_count) : dim3(level_count, B), dim3(QT_THREADS), smem, s, g, dense,
                        cand_count, lvl_kp, lvl_count, status, knode_glob, ncap, lds_keys, level_begin);
 }
 hipError_t orbx_quadtree_prepare(size_t smem) {
@@ -2231,14 +2196,11 @@ void orbx_launch_grid_build(hipStream_t s, const DGrid &gp, int nframes, const o
     hipLaunchKernelGGL(k_grid_build, dim3(nframes), dim3(1024), 0, s, gp, kps, counts, fixed_n, cap, cell_begin, items);
 }
 void orbx_launch_gate(hipStream_t s, const DGrid &gp, const orbx_keypoint *kps, const uint8_t *desc, const int *cell_begin,
-                      const uint16_t *items, const DGateQuery *q, const uint8_t *qdesc, int nq, uint32_t *begin, uint32_t *out_items,
-                      bool fill) {
+                      const uint16_t *items, const DGateQuery *q, const uint8_t *qdesc, int nq, uint2 *span, uint32_t *cursor,
+                      uint32_t *out_items, uint32_t cap) {
     if (nq <= 0) return;
-    if (fill) hipLaunchKernelGGL(k_gate<true>, dim3((nq + 3) / 4), dim3(256), 0, s, gp, kps, desc, cell_begin, items, q, qdesc, nq, begin, out_items);
-    else hipLaunchKernelGGL(k_gate<false>, dim3((nq + 3) / 4), dim3(256), 0, s, gp, kps, desc, cell_begin, items, q, qdesc, nq, begin, out_items);
-}
-void orbx_launch_scan_u32(hipStream_t s, uint32_t *a, int n) {
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, a, n);
+    hipLaunchKernelGGL(k_gate, dim3((nq + 3) / 4), dim3(256), 0, s, gp, kps, desc, cell_begin, items, q, qdesc, nq, span, cursor,
+                       out_items, cap);
 }
 void orbx_launch_block_dist(hipStream_t s, const uint8_t *d1, const uint8_t *d2, const DDistRow *rows, const uint32_t *col_idx,
                             int nrows, uint16_t *out) {
