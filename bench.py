@@ -17,7 +17,6 @@ By default the steps run one after the other on one pipeline (handle + HIP strea
 chip with its neighbours' kernels.  Weak scaling: every rank owns its own batch; no collective on the data path.
 """
 import argparse
-import hashlib
 import json
 import os
 import sys
@@ -82,10 +81,8 @@ def algorithmic_bytes(ex, w, h, n_kp, stereo):
 
 def kernels_hash():
     """identity of the device code the committed PMC counters were taken on"""
-    h = hashlib.sha256()
-    for f in ("orbx_kernels.hip", "orbx_device.h"):
-        h.update(open(os.path.join(ROOT, "orb_slam2_detailed_comments_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    from orb_slam2_detailed_comments_amd import build
+    return build.kernels_hash()
 
 
 def committed_counters(kind, cfg_name, B, W, H, NF):
@@ -146,6 +143,10 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="extract+match pipelines per GPU (handle + HIP stream each), used round-robin over the steps (mono "
                          "configs).  The default 1 keeps per-kernel durations un-overlapped")
+    ap.add_argument("--fork-level", type=int, default=0,
+                    help="ORBX_FORK_LEVEL for the extractor handles: levels >= N are resized (and their FAST groups run) on the handle's "
+                         "side stream next to the FAST kernel of the large levels (+3..5 %% frames/s at 3; DESIGN.md section 6).  0 = off "
+                         "(default): every kernel then runs alone and its duration is its own")
     ap.add_argument("--gather", default="gather", choices=("gather", "all_gather"),
                     help="collective for the per-frame keypoint records: to rank 0 (default) or to every rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -153,6 +154,8 @@ def main():
     ap.add_argument("--stages", action="store_true", help="also print a per-kernel table to stderr")
     args = ap.parse_args()
 
+    if args.fork_level > 0:
+        os.environ["ORBX_FORK_LEVEL"] = str(args.fork_level)   # read by the library when a handle is configured
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -322,7 +325,7 @@ def main():
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": kind, "name": args.config, "frames_per_gpu_per_step": B, "mean_keypoints": round(n_kp, 1),
+            "config": {"workload": kind + (f", fork level {os.environ['ORBX_FORK_LEVEL']}" if int(os.environ.get("ORBX_FORK_LEVEL", "0")) > 0 else ""), "name": args.config, "frames_per_gpu_per_step": B, "mean_keypoints": round(n_kp, 1),
                        "images_per_s": round(fps * imgs_per_unit, 1),
                        "parallelism": f"frames sharded x{world}, RCCL {args.gather} of keypoint records per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -338,7 +341,8 @@ def main():
                          "end_to_end_fused_GBs": round(total_fused * fps / world / 1e9, 2),
                          "end_to_end_fused_frac": round(total_fused * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_step": {k: round(v[0] / 2, 4) for k, v in prof.items()},
-            "kernel_ms_overlapped": NS > 1,   # with several pipelines the per-kernel durations include time shared with other kernels
+            # with several pipelines, or the forked launch sequence, per-kernel durations include time shared with other kernels
+            "kernel_ms_overlapped": NS > 1 or int(os.environ.get("ORBX_FORK_LEVEL", "0")) > 0,
         }
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only (the other ranks would idle through it)
             cfps, nsample, pinned = cpu_baseline(frames, right, NF, stereo, mb, mbf)

@@ -18,6 +18,16 @@ HEADERS = ["orbx_device.h", "orbx_internal.h", "orbx_launch.h", "orbx_sincos.h",
            os.path.join("..", "..", "include", "orbx.h"), os.path.join("..", "..", "include", "orbx_pattern_data.h")]
 
 
+def kernels_hash():
+    """identity of the device code (kernel source + device header): profiles/*_traffic.json and *_sq.json carry it, so counters
+    taken on other kernels read as 'not measured' in bench.py instead of as stale numbers"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("orbx_kernels.hip", "orbx_device.h"):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def hipcc():
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):

@@ -1194,9 +1194,8 @@ __constant__ uint32_t c_orient_w[64][12];
 #define DS_WPB 1   // waves (= keypoints) per block.  Nothing is shared between the waves of a block; one-wave blocks let the
                    // dispatcher place every wave as soon as any SIMD has room: 282 us against 299 (4 waves) and 372 (8)
 #endif
-#ifndef DS_KPW
-#define DS_KPW 1   // keypoints per wave, processed one after the other
-#endif
+// (Two or four consecutive keypoints per wave through the same LDS buffers, without prefetch, measured 314 / 319 us against
+// 282 us in round 2: the kernel is not bound by the launch rate of its one-wave workgroups.)
 #ifndef DS_WPS
 #define DS_WPS 7   // waves per SIMD the register allocation must allow (LDS admits 7 blocks of 4 waves per CU)
 #endif
@@ -1205,12 +1204,42 @@ __constant__ uint32_t c_orient_w[64][12];
 // LDS round trips, and resident waves are what hides them.)
 // FPM (fp_mode) is a template constant: as a run-time value it costs a scalar branch and both code paths in each of the 8 taps
 typedef const __attribute__((address_space(3))) uint16_t *orbx_lds_u16p;
-// one keypoint = one pass of a wave over its two LDS buffers
 template <int FPM>
-__device__ __forceinline__ void ds_one_keypoint(const DGeom &g, const uint8_t *__restrict__ pyr, const uint32_t *__restrict__ lvl_kp,
-                                                float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
-                                                uint8_t *__restrict__ desc, int cap, int dbg_stop, int f, int oi, int level, int slot,
-                                                int lane, uint32_t *patch, uint16_t *hrow) {
+__global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
+                                                  const uint32_t *__restrict__ lvl_kp,
+                                                  const int *__restrict__ lvl_count,
+                                                  float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
+                                                  uint8_t *__restrict__ desc, int *__restrict__ counts,
+                                                  int *__restrict__ status, int cap, int dbg_stop) {
+    // dbg_stop (ORBX_DESC_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS): 1 = after staging, 2 = after orientation,
+    // 3 = after the row pass.  The shipped library pins it to 0.
+#ifndef ORBX_TIMING_KNOBS
+    dbg_stop = 0;
+#endif
+    __shared__ uint32_t s_patch[DS_WPB][DS_W * DS_PP / 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[DS_WPB][DS_W * DS_HC];
+    // one wave per keypoint, waves indexed by dense OUTPUT position (level-major order of operator(), :2066-2082).
+    // The wave index is wave-uniform (which the compiler cannot see): with it scalar, the level search and the position
+    // load run on the scalar unit.
+    const int lane = threadIdx.x & 63, wv_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int f = blockIdx.x;   // frame fastest: one frame's patches stay in one XCD's L2
+    const int oi = blockIdx.y * DS_WPB + wv_id;
+    const int *lc = lvl_count + f * g.nlevels;
+    int total = 0, level = 0, slot = oi;
+#pragma unroll
+    for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
+        if (l < g.nlevels) {
+            if (oi >= total) { level = l; slot = g.lv[l].kp_begin + (oi - total); }
+            total += lc[l];
+        }
+    }
+    if (blockIdx.y == 0 && wv_id == 0 && lane == 0) {
+        counts[f] = min(total, cap);
+        if (total > cap) atomicMax(&status[f], (int)ORBX_CAPACITY);
+    }
+    if (oi >= min(total, cap) || dbg_stop == 4) return;
+    uint32_t *patch = s_patch[wv_id];
+    uint16_t *hrow = s_h[wv_id];
     const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];
     const int4 pat = c_pattern_lane[lane];
     const DLevel &L = g.lv[level];
@@ -1399,56 +1428,6 @@ __device__ __forceinline__ void ds_one_keypoint(const DGeom &g, const uint8_t *_
             kp.class_id = -1;
             kps[(long long)f * cap + oi] = kp;
         }
-    }
-}
-
-template <int FPM>
-__global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
-                                                  const uint32_t *__restrict__ lvl_kp,
-                                                  const int *__restrict__ lvl_count,
-                                                  float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
-                                                  uint8_t *__restrict__ desc, int *__restrict__ counts,
-                                                  int *__restrict__ status, int cap, int dbg_stop) {
-    // dbg_stop (ORBX_DESC_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS): 1 = after staging, 2 = after orientation,
-    // 3 = after the row pass.  The shipped library pins it to 0.
-#ifndef ORBX_TIMING_KNOBS
-    dbg_stop = 0;
-#endif
-    __shared__ uint32_t s_patch[DS_WPB][DS_W * DS_PP / 4 + 4];
-    __shared__ __attribute__((aligned(16))) uint16_t s_h[DS_WPB][DS_W * DS_HC];
-    // one wave per keypoint, waves indexed by dense OUTPUT position (level-major order of operator(), :2066-2082).
-    // The wave index is wave-uniform (which the compiler cannot see): with it scalar, the level search and the position
-    // load run on the scalar unit.
-    const int lane = threadIdx.x & 63, wv_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int f = blockIdx.x;   // frame fastest: one frame's patches stay in one XCD's L2
-    // DS_KPW consecutive output positions per wave, one after the other through the same LDS buffers: the launch of 258 k
-    // one-wave workgroups per 256 frames is itself ~60 us of this kernel (wave launch rate), and a second keypoint costs no
-    // registers (nothing of the next keypoint is prefetched -- that variant lost to the occupancy it costs)
-    const int oi0 = (blockIdx.y * DS_WPB + wv_id) * DS_KPW;
-    const int *lc = lvl_count + f * g.nlevels;
-    int total = 0;
-    int lend[ORBX_MAX_LEVELS];   // running totals (scalar registers)
-#pragma unroll
-    for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
-        if (l < g.nlevels) total += lc[l];
-        lend[l] = total;
-    }
-    if (blockIdx.y == 0 && wv_id == 0 && lane == 0) {
-        counts[f] = min(total, cap);
-        if (total > cap) atomicMax(&status[f], (int)ORBX_CAPACITY);
-    }
-    if (dbg_stop == 4) return;
-    uint32_t *patch = s_patch[wv_id];
-    uint16_t *hrow = s_h[wv_id];
-    for (int kk = 0; kk < DS_KPW; ++kk) {
-        const int oi = oi0 + kk;
-        if (oi >= min(total, cap)) return;
-        int level = 0, slot = oi;
-#pragma unroll
-        for (int l = 1; l < ORBX_MAX_LEVELS; ++l)
-            if (l < g.nlevels && oi >= lend[l - 1]) { level = l; slot = g.lv[l].kp_begin + (oi - lend[l - 1]); }
-        if (kk > 0) orbx_wave_sync();   // the previous keypoint's LDS reads are done before its buffers are overwritten
-        ds_one_keypoint<FPM>(g, pyr, lvl_kp, lvl_angle, kps, desc, cap, dbg_stop, f, oi, level, slot, lane, patch, hrow);
     }
 }
 
@@ -2184,7 +2163,7 @@ void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *p
 #else
     const int dbg_stop = 0;
 #endif
-    const dim3 grid(B, (g.kp_total + DS_WPB * DS_KPW - 1) / (DS_WPB * DS_KPW));
+    const dim3 grid(B, (g.kp_total + DS_WPB - 1) / DS_WPB);
     if (g.fp_mode == ORBX_FP_GCC_FMA)
         hipLaunchKernelGGL(k_describe<ORBX_FP_GCC_FMA>, grid, dim3(64 * DS_WPB), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
     else

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""profiles/r01_traffic.json from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/pmc_probe.py.
+"""profiles/r0N_traffic.json from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/pmc_probe.py.
 
   tools/make_traffic_json.py FETCH_DIR WRITE_DIR OUT.json [batch width height nfeatures]
 
 HBM bytes per launch = FETCH_SIZE[KB] * 1024 * 2 (gfx950 calibration, tools/fetch_calib.hip) + WRITE_SIZE[KB] * 1024.
 Entries are keyed by the profiling slot bench.py uses (k_pyr_l0, k_pyr_resize, k_fast_rows, ...); the device kernels
 behind a slot are summed (k_match = k_match + k_match_merge) and listed."""
-import csv, collections, glob, json, sys
+import csv, collections, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from orb_slam2_detailed_comments_amd import build
 
 SLOTS = {
     "k_pyr_l0": ["k_pyr_l0", "k_pyr_l0_color"],
@@ -47,7 +49,7 @@ def main():
             "hbm_bytes_per_launch": int((f_kb * 2.0 + w_kb) * 1024 / launches),
         }
     total = sum(k["hbm_bytes_per_launch"] * k["launches_per_step"] for k in kernels.values())
-    json.dump({"batch": B, "width": W, "height": H, "nfeatures": NF, "steps_profiled": steps,
+    json.dump({"config": "tum", "kernels_sha256_16": build.kernels_hash(), "batch": B, "width": W, "height": H, "nfeatures": NF, "steps_profiled": steps,
                "calibration": {"FETCH_SIZE_factor": 2.0, "WRITE_SIZE_factor": 1.0,
                                "how": "tools/fetch_calib.hip streams 512 MiB once with 4 B/lane, 16 B/lane and 64-byte row "
                                       "segments: FETCH_SIZE reports exactly 1/2 for all three, WRITE_SIZE is exact"},
