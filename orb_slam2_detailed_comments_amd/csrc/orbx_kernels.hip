@@ -1196,6 +1196,13 @@ __constant__ uint32_t c_orient_w[64][12];
 #endif
 // (Two or four consecutive keypoints per wave through the same LDS buffers, without prefetch, measured 314 / 319 us against
 // 282 us in round 2: the kernel is not bound by the launch rate of its one-wave workgroups.)
+// (Round 2 also rebuilt the column pass around the LDS counters -- the LDS pipe is active 87 % of this kernel, 60 % of that
+// bank conflicts of the 56 ds_read_u16 per lane at the rotated tap positions: row-pass output stored TRANSPOSED in two
+// copies (A[c][r] = h[r][c], B[c][r] = h[r + 2][c]) so that a tap's seven vertical neighbours always sit in one 8-byte
+// aligned 16-byte window, fetched by ONE ds_read2_b64 and folded by v_alignbit + four v_dot2_u32_u16; the patch aliased
+// into copy B.  Bit-exact, 8 instead of 56 LDS reads per lane -- and 324 us against 281 us: the transposed stores and the
+// window addressing cost ~95 more vector instructions per keypoint, and with both pipes near saturation it is the vector
+// pipe that sets the time.  Not kept.)
 #ifndef DS_WPS
 #define DS_WPS 7   // waves per SIMD the register allocation must allow (LDS admits 7 blocks of 4 waves per CU)
 #endif

@@ -47,5 +47,31 @@ while time.time() - t0 < budget:
             ref = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2).astype(np.uint16) if nq and nt else np.zeros((nq, nt), np.uint16)
             assert np.array_equal(D, ref), f"matrix nq={nq} nt={nt}"
         nm += 1
+    # ---- device grid + gated candidate lists (the primitive behind every projection-guided policy) against the oracle's
+    # GetFeaturesInArea + DescriptorDistance: random bounds (keypoints partly outside), radii, level-argument forms
+    import ctypes as C
+    kk = kL.copy()
+    nk = len(kk)
+    if nk:
+        bx0, by0 = float(rng.uniform(-20, 60)), float(rng.uniform(-20, 60))
+        bounds = np.array([bx0, bx0 + float(rng.uniform(0.5, 1.2)) * w, by0, by0 + float(rng.uniform(0.5, 1.2)) * h], np.float32)
+        nq = int(rng.integers(1, 400))
+        xyr = np.zeros((nq, 3), np.float32); lv = np.zeros((nq, 2), np.int32)
+        xyr[:, 0] = rng.uniform(-50, w + 50, nq); xyr[:, 1] = rng.uniform(-50, h + 50, nq)
+        xyr[:, 2] = rng.choice([-1.0, 0.5, 4.0, 9.9, 25.0, 80.0, 300.0], nq)
+        lv[:, 0] = rng.integers(-1, nl + 1, nq); lv[:, 1] = rng.integers(-1, nl + 1, nq)
+        qd = dR[rng.integers(0, max(len(dR), 1), nq)].copy() if len(dR) else np.zeros((nq, 32), np.uint8)
+        begin = np.zeros(nq + 1, np.uint32); items = np.zeros(max(nq * nk, 1), np.uint32); tot = C.c_int(0)
+        _capi.check(_capi.lib().orbx_gated_candidates(exL.handle, _capi.ptr(kk), _capi.ptr(dL), nk, _capi.ptr(bounds), _capi.ptr(xyr),
+                                                      _capi.ptr(lv), _capi.ptr(qd), nq, _capi.ptr(begin), _capi.ptr(items), len(items), C.byref(tot)))
+        for i in range(nq):
+            got = items[begin[i]:begin[i + 1]]
+            want = oracle.grid_query(kk, tuple(bounds), float(xyr[i, 0]), float(xyr[i, 1]), float(xyr[i, 2]), int(lv[i, 0]), int(lv[i, 1])) if xyr[i, 2] >= 0 else np.zeros(0, np.int32)
+            assert np.array_equal(got & 0xffff, want.astype(np.uint32)), f"gate query {i} ({xyr[i]}, {lv[i]}) bounds {bounds}: {tag}"
+            if len(want):
+                j = int(rng.integers(0, len(want)))
+                assert int(got[j] >> 16) == oracle.descriptor_distance(qd[i], dL[want[j]]), f"gate distance: {tag}"
+        ng = globals().get("ng", 0) + nq
     if ns % 20 == 0: print(f"  .. {ns} stereo pairs, {nm} descriptor sets, {time.time() - t0:.0f} s", flush=True)
+print(f"gated candidate queries compared: {globals().get('ng', 0)}")
 print(f"policy soak ok: {ns} random stereo pairs ({skipped} unsupported geometries skipped), {nm} random descriptor-set matches in {time.time() - t0:.0f} s")
