@@ -21,7 +21,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $o/r02_${tag}_prof_kitti
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/r02_${tag}_pmc_fetch -- python3 tools/pmc_probe.py 256 > $o/r02_${tag}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/r02_${tag}_pmc_write -- python3 tools/pmc_probe.py 256 > $o/r02_${tag}_pmc_write.log 2>&1
 bash tools/pmc_passes.sh $o/r02_${tag}_pmc_sq > $o/r02_${tag}_pmc_sq.log 2>&1
-b() { t=$1; shift; env "$@" python bench.py --no-cpu-baseline --stages > $o/r02_${tag}_v_$t.log 2>&1; echo "== $t"; grep -E "k_quad" $o/r02_${tag}_v_$t.log | tr -s ' ' | cut -d' ' -f2,3 | tr '\n' ' '; tail -1 $o/r02_${tag}_v_$t.log | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'])"; }
-for v in qt128 qt512; do b $v ORBX_LIB=$PWD/tools/bin/liborbx_$v.so; done
-b keys2000 ORBX_QT_LDS_KEYS=2000
 echo profiles done
