@@ -146,6 +146,8 @@ static void prof_drain(orbx_handle *h) {
     h->pending.clear();
 }
 
+static orbx_status pin_reserve(orbx_handle *h, size_t bytes);   // page-locked host staging (defined with the policy plumbing)
+
 // ---------------------------------------------------------------- workspace
 static void free_geometry_buffers(orbx_handle *h) {
     hipFree(h->d_groups); h->d_groups = nullptr;
@@ -334,7 +336,7 @@ extern "C" void orbx_destroy(orbx_handle *h) {
         hipFree(h->d_match_ws); hipFree(h->d_scratch); hipFree(h->d_rect); hipFree(h->d_gate_items);
         if (h->pin) hipHostFree(h->pin);
         for (int s = 0; s < 2; ++s) {
-            hipFree(h->st_in[s]); hipFree(h->st_kps[s]); hipFree(h->st_desc[s]); hipFree(h->st_cnt[s]);
+            hipFree(h->st_in[s]); hipFree(h->st_kps[s]);   // st_desc / st_cnt live inside the st_kps allocation
             if (h->ev_in[s]) hipEventDestroy(h->ev_in[s]);
             if (h->ev_done[s]) hipEventDestroy(h->ev_done[s]);
         }
@@ -518,15 +520,18 @@ static orbx_status ensure_staging(orbx_handle *h, size_t in_bytes, int cap, int 
         const size_t inb = std::max(in_bytes, h->d_in_bytes);
         const int c = std::max(cap, h->out_cap), ch = std::max(chunk, h->stage_chunk);
         for (int s = 0; s < 2; ++s) {
-            hipFree(h->st_in[s]); hipFree(h->st_kps[s]); hipFree(h->st_desc[s]); hipFree(h->st_cnt[s]);
+            hipFree(h->st_in[s]); hipFree(h->st_kps[s]);   // st_desc / st_cnt live inside the st_kps allocation
             h->st_in[s] = nullptr; h->st_kps[s] = nullptr; h->st_desc[s] = nullptr; h->st_cnt[s] = nullptr;
         }
         h->d_in_bytes = 0; h->out_cap = 0; h->stage_chunk = 0;
         for (int s = 0; s < 2; ++s) {
             HIPCHK(hipMalloc(&h->st_in[s], inb));
-            HIPCHK(hipMalloc(&h->st_kps[s], (size_t)ch * c * sizeof(orbx_keypoint)));
-            HIPCHK(hipMalloc(&h->st_desc[s], (size_t)ch * c * 32));
-            HIPCHK(hipMalloc(&h->st_cnt[s], (size_t)2 * ch * sizeof(int)));   // counts | status
+            // one block per set: keypoints | descriptors | counts | status -- a call that fills the block exactly (the
+            // single-frame drop-in call) downloads it with ONE copy
+            const size_t kb = (size_t)ch * c * sizeof(orbx_keypoint), db = (size_t)ch * c * 32;
+            uint8_t *blk = nullptr;
+            HIPCHK(hipMalloc(&blk, kb + db + (size_t)2 * ch * sizeof(int)));
+            h->st_kps[s] = (orbx_keypoint *)blk; h->st_desc[s] = blk + kb; h->st_cnt[s] = (int *)(blk + kb + db);
         }
         h->d_in_bytes = inb; h->out_cap = c; h->stage_chunk = ch;
     }
@@ -601,6 +606,40 @@ extern "C" orbx_status orbx_extract_batch(orbx_handle *h, int nframes, const uin
                 if (hstat[(size_t)s * chunk + i] != ORBX_OK) worst = (orbx_status)hstat[(size_t)s * chunk + i];
         return e;
     };
+    // Latency path (one chunk that fills its staging block exactly, a few MB at most -- the drop-in call of Tracking.cc): the
+    // frames go through page-locked staging (one true DMA instead of a runtime-staged pageable copy) and the results come
+    // back with ONE copy of the whole output block instead of four.
+    const size_t out_bytes = (size_t)chunk * cap * (sizeof(orbx_keypoint) + 32) + (size_t)2 * chunk * sizeof(int);
+    const size_t in_bytes_q = (size_t)nframes * fbytes;
+    const bool stage_in = in_bytes_q <= ((size_t)1 << 20);   // beyond ~1 MB the host-side memcpy costs more than the runtime's own staging
+    const bool quick = !piped && nframes == h->stage_chunk && cap == h->out_cap && out_bytes <= ((size_t)4 << 20) &&
+                       pin_reserve(h, (stage_in ? in_bytes_q : 0) + out_bytes) == ORBX_OK;
+    if (quick) {
+        uint8_t *pin_in = h->pin, *pin_out = h->pin + (stage_in ? in_bytes_q : 0);
+        if (stage_in) {
+            for (int i = 0; i < nframes; ++i) memcpy(pin_in + (size_t)i * fbytes, imgs + (int64_t)i * frame_stride, fbytes);
+            HIPCHK(hipMemcpyAsync(h->st_in[0], pin_in, in_bytes_q, hipMemcpyHostToDevice, h->stream));
+        } else {
+            HIPCHK(upload(0));
+        }
+        st = run_chunk(h, nframes, h->st_in[0], width, height, stride, (int64_t)fbytes, h->st_kps[0], h->st_desc[0], h->st_cnt[0],
+                       h->st_cnt[0] + chunk, cap);
+        if (st != ORBX_OK) { hipStreamSynchronize(h->stream); return st; }
+        HIPCHK(hipMemcpyAsync(pin_out, h->st_kps[0], out_bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const size_t kb = (size_t)nframes * cap * sizeof(orbx_keypoint), db = (size_t)nframes * cap * 32;
+        const int *cnt = (const int *)(pin_out + kb + db);
+        // only the meaningful part of every frame's records leaves the staging buffer
+        for (int i = 0; i < nframes; ++i) {
+            const int n = std::min(std::max(cnt[i], 0), cap);
+            memcpy(kps + (int64_t)i * cap, pin_out + (size_t)i * cap * sizeof(orbx_keypoint), (size_t)n * sizeof(orbx_keypoint));
+            memcpy(desc + (int64_t)i * cap * 32, pin_out + kb + (size_t)i * cap * 32, (size_t)n * 32);
+            counts[i] = cnt[i];
+            if (cnt[nframes + i] != ORBX_OK) worst = (orbx_status)cnt[nframes + i];
+        }
+        if (worst != ORBX_OK) return fail(worst, "a frame exceeded the keypoint / candidate capacity");
+        return ORBX_OK;
+    }
     HIPCHK(upload(0));
     for (int c = 0; c < nchunks; ++c) {
         const int s = c & 1, f0 = c * chunk, B = std::min(chunk, nframes - f0);
