@@ -209,12 +209,16 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     {
         const size_t want = std::min<size_t>({(size_t)4096, (size_t)g.max_cand_cap, (size_t)6 * (size_t)std::max(g.lv[0].nfeat, 1)});
         size_t keys = 0;
-        for (int wg = 4; wg >= 1 && keys == 0; --wg) {
+        auto fit_at = [&](int wg) -> size_t {
             const size_t budget = (size_t)(160 * 1024) / wg - 512;   // allocation granularity margin
-            if (budget <= node_part) continue;
-            const size_t fit = std::min<size_t>({(budget - node_part) / 6, (size_t)4096, (size_t)g.max_cand_cap});
-            if (fit >= want || wg == 1) keys = fit;
-        }
+            return budget <= node_part ? 0 : std::min<size_t>({(budget - node_part) / 6, (size_t)4096, (size_t)g.max_cand_cap});
+        };
+        for (int wg = 4; wg >= 2 && keys == 0; --wg)
+            if (fit_at(wg) >= want) keys = fit_at(wg);
+        // large nfeatures (node tables of tens of KB): two workgroups per CU with the dense levels on the global key map beat
+        // one workgroup with every level in LDS -- those levels exceed any LDS budget anyway
+        if (keys == 0 && fit_at(2) >= 1024) keys = fit_at(2);
+        if (keys == 0) keys = fit_at(1);
         if (const char *e = getenv("ORBX_QT_LDS_KEYS")) keys = std::min<size_t>((size_t)std::max(atoi(e), 0), std::min<size_t>(8192, (160 * 1024 - node_part) / 6));
         h->lds_keys = (int)keys;
     }

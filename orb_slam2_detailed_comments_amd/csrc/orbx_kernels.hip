@@ -779,18 +779,20 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
 //   * the address tie-break of std::sort over pair<int,ExtractorNode*> is defined as creation order (F3).
 // Selection (:1387-1413) = max response, first in emission order, via one 64-bit LDS atomicMax per key.
 // ------------------------------------------------------------------------------------------------
-#ifndef QT_THREADS
-#define QT_THREADS 256   // round 2: with the key slots sized for 4 workgroups per CU, 256 threads beat 512 (99 vs 117 us per 256 frames)
-#endif
+// Workgroup size is a template parameter, picked per launch (orbx_launch_quadtree): the kernel is a chain of barrier-separated
+// stages, so many small workgroups win when the launch has several workgroups per CU to choose from (256 threads: 67 us per
+// 256 frames of 640x480 / 1000 features against 82 us with 512), and large ones when there are few workgroups with many keys
+// each (1920x1080 / 4000 features, 32 frames = one workgroup per CU: 185 / 112 / 82 us with 256 / 512 / 1024 threads).
 
 struct QtShared {
     int size, prev_size, n_expand, ctot, nmtot, jstar, m, finish;
-    uint32_t wsum[QT_THREADS / 64];
+    uint32_t wsum[16];   // one per wave, up to 1024 threads
     uint32_t carry;
 };
 
 // exclusive prefix sum of in[0..n) -> out[0..n) (both LDS, may alias), returns total; all threads must call.
 // Two barriers per 512-element chunk: wave scan -> wave totals in LDS -> every thread adds the totals before it.
+template <int QT_THREADS>
 __device__ uint32_t qt_block_scan(const uint32_t *in, uint32_t *out, int n, QtShared *sh) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint32_t carry = 0;
@@ -830,6 +832,7 @@ __device__ __forceinline__ void qt_child_box(uint32_t b0, uint32_t b1, int q, ui
     c1 = (uint32_t)cx1 | ((uint32_t)cy1 << 16);
 }
 
+template <int QT_THREADS>
 __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *__restrict__ dense_all,
                                                         const int *__restrict__ cand_count,
                                                         uint32_t *__restrict__ lvl_kp, int *__restrict__ lvl_count,
@@ -849,8 +852,6 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *_
     // ---- LDS carve-up (all arrays have ncap entries unless noted)
     uint8_t *sp = qt_smem;
     QtShared *sh = (QtShared *)sp;                 sp += 128;
-    sp += 4 * QT_THREADS;   // (reserved: keeps orbx_quadtree_smem's layout)
-    unsigned long long *best = (unsigned long long *)sp; sp += 8 * (size_t)ncap;
     uint32_t *boxA0 = (uint32_t *)sp;              sp += 4 * (size_t)ncap;
     uint32_t *boxA1 = (uint32_t *)sp;              sp += 4 * (size_t)ncap;
     uint32_t *cntA = (uint32_t *)sp;               sp += 4 * (size_t)ncap;
@@ -860,7 +861,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *_
     uint32_t *cntB = (uint32_t *)sp;               sp += 4 * (size_t)ncap;
     uint32_t *metaB = (uint32_t *)sp;              sp += 4 * (size_t)ncap;
     uint32_t *cc = (uint32_t *)sp;                 sp += 16 * (size_t)ncap;  // [ncap][4] quadrant counts
-    uint32_t *newpos = (uint32_t *)sp;             sp += 16 * (size_t)ncap;  // [ncap][4] child list positions; [p][0] for survivors
+    unsigned long long *best = (unsigned long long *)cc;                      // selection keys: the quadrant counts are dead by then
+    uint16_t *newpos = (uint16_t *)sp;             sp += 8 * (size_t)ncap + 16;  // [ncap][4] child list positions (< ncap); [p][0] for survivors
     uint32_t *t0 = (uint32_t *)sp;                 sp += 4 * (size_t)ncap;   // scan input
     uint32_t *t1 = (uint32_t *)sp;                 sp += 4 * (size_t)ncap;   // scan output E
     uint32_t *t2 = (uint32_t *)sp;                 sp += 4 * (size_t)ncap;   // scan output NM
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *_
                 t0[p] = ne | (nx << 16);
             }
             __syncthreads();
-            const uint32_t tot = qt_block_scan(t0, t1, size, sh);
+            const uint32_t tot = qt_block_scan<QT_THREADS>(t0, t1, size, sh);
             ctot = tot & 0xffff;
             nexp_total = tot >> 16;
             for (int p = tid; p < size; p += QT_THREADS) {
@@ -948,15 +950,15 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *_
                 t3[p] = 1;  // processed flag for expandable nodes: all of them
             }
             __syncthreads();
-            nmtot = (int)qt_block_scan(t0, t2, size, sh);
+            nmtot = (int)qt_block_scan<QT_THREADS>(t0, t2, size, sh);
         } else {
             // careful phase: order candidates by descending (count, creation rank).  The candidate keys are first
             // compacted into a dense, 16-byte aligned LDS array (scratch = newpos, rewritten in phase D anyway); each
             // candidate then counts the larger keys with ds_read_b128 over M/4 steps instead of walking the whole list.
-            uint32_t *dk = newpos, *dp = newpos + 2 * (size_t)ncap;   // dense keys [M + 4], back references [M]
+            uint32_t *dk = (uint32_t *)newpos, *dp = dk + (size_t)ncap + 4;   // dense keys [M + 4], back references [M]: 8 ncap + 16 bytes
             for (int p = tid; p < size; p += QT_THREADS) { t0[p] = (meta[p] >> 16) & 1; t3[p] = 0xffffffffu; }
             __syncthreads();
-            const int Mc = (int)qt_block_scan(t0, t1, size, sh);
+            const int Mc = (int)qt_block_scan<QT_THREADS>(t0, t1, size, sh);
             for (int p = tid; p < size; p += QT_THREADS)
                 if ((meta[p] >> 16) & 1) { dk[t1[p]] = (cnt[p] << 16) | (meta[p] & 0xffffu); dp[t1[p]] = p; }
             if (tid < 4) dk[Mc + tid] = 0u;   // padding compares as "not larger"
@@ -983,7 +985,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *_
             }
             __syncthreads();
             const int M = sh->m;
-            qt_block_scan(t4, t5, M, sh);  // exclusive, packed: CE (low 16) | sum(ne-1) before (high 16)
+            qt_block_scan<QT_THREADS>(t4, t5, M, sh);  // exclusive, packed: CE (low 16) | sum(ne-1) before (high 16)
             for (int r = tid; r < M; r += QT_THREADS) {
                 const int after = size + (int)(t5[r] >> 16) + (int)(t4[r] >> 16);  // list size after splitting rank r
                 if (after >= N) atomicMin(&sh->jstar, r);
@@ -1000,7 +1002,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *_
                 meta[p] = (meta[p] & 0xffffu) | ((uint32_t)proc << 16);
             }
             __syncthreads();
-            nmtot = (int)qt_block_scan(t0, t2, size, sh);
+            nmtot = (int)qt_block_scan<QT_THREADS>(t0, t2, size, sh);
         }
         // ---- D: build the next list (push_front order: child with creation rank r sits at ctot-1-r)
         for (int p = tid; p < size; p += QT_THREADS) {
@@ -1014,7 +1016,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *_
                         qt_child_box(box0[p], box1[p], q, c0, c1);
                         nbox0[pos] = c0; nbox1[pos] = c1; ncnt[pos] = c;
                         nmeta[pos] = (uint32_t)r | ((uint32_t)(c > 1) << 16);
-                        newpos[4 * p + q] = pos;
+                        newpos[4 * p + q] = (uint16_t)pos;
                         ++r;
                     }
                 }
@@ -1022,7 +1024,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DGeom g, const uint2 *_
                 const int pos = ctot + (int)t2[p];
                 nbox0[pos] = box0[p]; nbox1[pos] = box1[p]; ncnt[pos] = cnt[p];
                 nmeta[pos] = 0;
-                newpos[4 * p] = pos;
+                newpos[4 * p] = (uint16_t)pos;
             }
         }
         __syncthreads();
@@ -2055,7 +2057,7 @@ hipError_t orbx_upload_pattern() {
 }
 
 size_t orbx_quadtree_smem(int ncap, int lds_keys) {
-    return 128 + 4 * QT_THREADS + (size_t)ncap * (8 + 8 * 4 + 16 + 16 + 6 * 4) + (size_t)lds_keys * 6 + 16;
+    return 128 + (size_t)ncap * (8 * 4 + 16 + 8 + 6 * 4) + 16 + (size_t)lds_keys * 6 + 16;
 }
 
 void orbx_launch_clear(hipStream_t s, int *a, int na, int *b, int nb, int *c, int nc) {
@@ -2137,12 +2139,24 @@ void orbx_launch_bow_transform(hipStream_t s, int B, int max_n, const int *child
     hipLaunchKernelGGL(k_bow_transform, dim3((max_n + 15) / 16, B), dim3(256), 0, s, v, desc, counts, frame_stride, levelsup,
                        out_leaf, out_nid, out_stride);
 }
+static int g_qt_cus = 0;   // CUs of the current device (orbx_quadtree_prepare)
 void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const uint2 *dense, const int *cand_count, uint32_t *lvl_kp, int *lvl_count,
                           int *status, uint16_t *knode_glob, int ncap, int lds_keys, int level_begin, int level_count) {
     if (level_count <= 0) return;
     const size_t smem = orbx_quadtree_smem(ncap, lds_keys);
-    hipLaunchKernelGGL(k_quadtree, QT_FF ? dim3(B, level_count) : dim3(level_count, B), dim3(QT_THREADS), smem, s, g, dense,
-                       cand_count, lvl_kp, lvl_count, status, knode_glob, ncap, lds_keys, level_begin);
+    // workgroups per CU of this launch decide the workgroup size (see k_quadtree)
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("ORBX_QT_THREADS"); forced = e ? atoi(e) : 0; }
+    const long long wgs = (long long)B * level_count, cus = g_qt_cus > 0 ? g_qt_cus : 256;
+    int threads = wgs >= 4 * cus ? 256 : wgs >= 2 * cus ? 512 : 1024;
+    if (forced == 256 || forced == 512 || forced == 1024) threads = forced;
+    const dim3 grid = QT_FF ? dim3(B, level_count) : dim3(level_count, B);
+    if (threads == 256)
+        hipLaunchKernelGGL(k_quadtree<256>, grid, dim3(256), smem, s, g, dense, cand_count, lvl_kp, lvl_count, status, knode_glob, ncap, lds_keys, level_begin);
+    else if (threads == 512)
+        hipLaunchKernelGGL(k_quadtree<512>, grid, dim3(512), smem, s, g, dense, cand_count, lvl_kp, lvl_count, status, knode_glob, ncap, lds_keys, level_begin);
+    else
+        hipLaunchKernelGGL(k_quadtree<1024>, grid, dim3(1024), smem, s, g, dense, cand_count, lvl_kp, lvl_count, status, knode_glob, ncap, lds_keys, level_begin);
 }
 hipError_t orbx_quadtree_prepare(size_t smem) {
     // The attribute belongs to (function, device), not to a handle: ORB-SLAM2 itself keeps mpIniORBextractor (2 x nFeatures)
@@ -2153,8 +2167,11 @@ hipError_t orbx_quadtree_prepare(size_t smem) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(mu);
+    if (g_qt_cus == 0) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) g_qt_cus = pr.multiProcessorCount; }
     if (dev >= 0 && dev < 64 && smem <= cur[dev]) return hipSuccess;
-    e = hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    e = hipFuncSetAttribute((const void *)k_quadtree<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_quadtree<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_quadtree<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess && dev >= 0 && dev < 64) cur[dev] = smem;
     return e;
 }
