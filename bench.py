@@ -147,6 +147,9 @@ def main():
                     help="ORBX_FORK_LEVEL for the extractor handles: levels >= N are resized (and their FAST groups run) on the handle's "
                          "side stream next to the FAST kernel of the large levels (+3..5 %% frames/s at 3; DESIGN.md section 6).  0 = off "
                          "(default): every kernel then runs alone and its duration is its own")
+    ap.add_argument("--stereo-streams", type=int, default=1, choices=(1, 2),
+                    help="stereo configs: 1 = both eyes' extractions on one stream (kernels run alone, durations are their own); "
+                         "2 = one stream per eye, as the reference's two extraction threads (overlapped durations)")
     ap.add_argument("--gather", default="gather", choices=("gather", "all_gather"),
                     help="collective for the per-frame keypoint records: to rank 0 (default) or to every rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -193,8 +196,10 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     for e, st in zip(exs, streams):
         e.set_stream(st.cuda_stream)
-    if stereo:
-        exR.set_stream(streams[0].cuda_stream)
+    stream_r = None
+    if stereo:   # the reference extracts the two eyes on two threads (src/Frame.cc:158-168): two handles; --stereo-streams 2 gives each its own stream
+        stream_r = torch.cuda.Stream(device=dev) if args.stereo_streams == 2 else streams[0]
+        exR.set_stream(stream_r.cuda_stream)
     # slot 0 of the result buffers carries the last frame of the previous step (match t vs t-1)
     bufs = []
     for _ in range(NS):
@@ -227,7 +232,8 @@ def main():
         with torch.cuda.stream(st):
             e.extract_batch_device(d_imgs, B, W, H, W, W * H, b["kps"][1:], b["desc"][1:], b["counts"][1:], b["status"], cap)
             if stereo:
-                exR.extract_batch_device(d_right, B, W, H, W, W * H, b["kpsR"], b["descR"], b["countsR"], b["statusR"], cap)
+                with torch.cuda.stream(stream_r):
+                    exR.extract_batch_device(d_right, B, W, H, W, W * H, b["kpsR"], b["descR"], b["countsR"], b["statusR"], cap)
                 _capi.check(L.orbx_stereo_match_batch_device(
                     e.handle, exR.handle, B, _capi.ptr(b["kps"][1:]), _capi.ptr(b["desc"][1:]), _capi.ptr(b["counts"][1:]),
                     _capi.ptr(b["kpsR"]), _capi.ptr(b["descR"]), _capi.ptr(b["countsR"]), cap, mb, mbf,
@@ -342,7 +348,7 @@ def main():
                          "end_to_end_fused_frac": round(total_fused * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
             "kernel_ms_per_step": {k: round(v[0] / 2, 4) for k, v in prof.items()},
             # with several pipelines, or the forked launch sequence, per-kernel durations include time shared with other kernels
-            "kernel_ms_overlapped": NS > 1 or int(os.environ.get("ORBX_FORK_LEVEL", "0")) > 0,
+            "kernel_ms_overlapped": NS > 1 or int(os.environ.get("ORBX_FORK_LEVEL", "0")) > 0 or (stereo and args.stereo_streams == 2),
         }
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only (the other ranks would idle through it)
             cfps, nsample, pinned = cpu_baseline(frames, right, NF, stereo, mb, mbf)

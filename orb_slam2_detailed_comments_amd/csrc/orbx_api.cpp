@@ -41,6 +41,7 @@ struct orbx_handle {
     // launches; they run here, next to the issue-bound FAST kernel of the large levels on the main stream
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_stereo = nullptr;   // orders the batched stereo match with the OTHER eye's stream (two extractors, two streams)
     int fork_level = 0;       // first level whose resize + FAST run on the side stream (0 = no fork)
     int fork_group = 0;       // first FAST group of that level
     // geometry-dependent device state
@@ -322,6 +323,7 @@ extern "C" orbx_status orbx_create(const orbx_params *params, orbx_handle **out)
         if (const char *ef = getenv("ORBX_EVENT_FLAGS")) evflags = (unsigned)strtoul(ef, nullptr, 0);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, evflags);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, evflags);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_stereo, evflags);
     }
     if (e != hipSuccess) { orbx_destroy(h); return fail(ORBX_HIP_ERROR, hipGetErrorString(e)); }
     h->stream = h->own_stream;
@@ -349,6 +351,7 @@ extern "C" void orbx_destroy(orbx_handle *h) {
         if (h->side_stream) { hipStreamSynchronize(h->side_stream); hipStreamDestroy(h->side_stream); }
         if (h->ev_fork) hipEventDestroy(h->ev_fork);
         if (h->ev_join) hipEventDestroy(h->ev_join);
+        if (h->ev_stereo) hipEventDestroy(h->ev_stereo);
         if (h->own_stream) hipStreamDestroy(h->own_stream);
     }
     delete h;
@@ -1309,7 +1312,13 @@ extern "C" orbx_status orbx_stereo_match_batch_device(orbx_handle *hl, orbx_hand
         hl->p.nlevels != hr->p.nlevels || hl->p.scale_factor != hr->p.scale_factor)
         return fail(ORBX_BAD_ARGUMENT, "left and right extractor must share device, image size and pyramid parameters");
     HIPCHK(hipSetDevice(hl->dev));
-    if (hr->stream != hl->stream) HIPCHK(hipStreamSynchronize(hr->stream));   // the right pyramids are read from the left stream
+    // The reference extracts the two eyes on two threads (src/Frame.cc:158-168); here that is two handles on two streams.  The
+    // match runs on the left stream: it waits for the right stream's work so far (an event, no host synchronisation) ...
+    const bool two_streams = hr->stream != hl->stream;
+    if (two_streams) {
+        HIPCHK(hipEventRecord(hr->ev_stereo, hr->stream));
+        HIPCHK(hipStreamWaitEvent(hl->stream, hr->ev_stereo, 0));
+    }
     OrbxStereoGeom sg;
     memset(&sg, 0, sizeof(sg));
     sg.nlevels = hl->p.nlevels; sg.nrows0 = hl->geom.lv[0].ph; sg.mb = mb; sg.mbf = mbf;
@@ -1328,6 +1337,10 @@ extern "C" orbx_status orbx_stereo_match_batch_device(orbx_handle *hl, orbx_hand
     { ProfScope ps(hl, ORBX_K_MATCH);
       orbx_launch_stereo_batch(hl->stream, sg, npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, hl->d_pyr, hr->d_pyr,
                                (long long)hl->geom.pyr_bytes, d_u_right, d_depth, dsad, d_nmatches, drow, ditems); }
+    if (two_streams) {   // ... and whatever the right stream does next (the next pair's pyramids) waits for the match that reads this one's
+        HIPCHK(hipEventRecord(hl->ev_stereo, hl->stream));
+        HIPCHK(hipStreamWaitEvent(hr->stream, hl->ev_stereo, 0));
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
     return ORBX_OK;
