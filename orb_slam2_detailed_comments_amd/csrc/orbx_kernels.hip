@@ -1442,54 +1442,162 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
 
 // ------------------------------------------------------------------------------------------------
 // K7: brute-force Hamming best / second-best (DescriptorDistance src/ORBmatcher.cc:2073-2093 for every
-// pair; bookkeeping of the search loops, e.g. :627-640).  Two queries per lane (16 dwords in VGPRs); the train
-// descriptor of an iteration is the same for the whole wave, so it is fetched with SCALAR loads (s_load_dwordx8
-// through the scalar cache) and used as the SGPR operand of v_xor: no LDS staging, no barrier, and the LDS pipe
-// (a broadcast ds_read_b128 per 8 xor/bcnt pairs was what bounded the first version) stays out of the loop.
+// pair; bookkeeping of the search loops, e.g. :627-640) on the matrix cores.
+//
+// nq x nt x 256 bit operations per pair is GEMM-shaped and compute-bound (16 MB of descriptors against 65 G bit
+// products per 256-frame step), so the distances come from v_mfma_i32_32x32x32_i8:
+//     dist(q, t) = popc(q) + popc(t) - 2 * <q, t>           (<.,.> = dot product of the two bit vectors)
+//   * A operand = 32 TRAIN descriptors of a tile, bit p of their 32 bytes expanded to bytes 0 / 64 (shift + and per
+//     dword; K-step p = bit p of every byte: the K order is irrelevant as long as both operands use the same one);
+//   * B operand = 32 QUERY descriptors, expanded ONCE per wave to bytes 0 / -128 and kept in registers (two query tiles
+//     per wave: 64 VGPRs), so that every product is 0 or -8192 = -2 << 12;
+//   * the accumulator of a tile is not cleared but LOADED with key(t) = (popc(t) + 256) << 12 | index-in-chunk from an
+//     LDS table (the C layout puts 4 consecutive train rows in 4 consecutive registers: one ds_read_b128 each), so
+//     eight MFMAs leave  key = (dist - popc(q) + 256) << 12 | index  in every accumulator register -- ordered like
+//     (dist, index) for the lane's query -- and the bookkeeping is two instructions per distance: second =
+//     med3(key, best, second), best = min(best, key).  min(key) is the best match with the lowest index on ties and the
+//     second-smallest key carries the second-best distance counting duplicates, exactly the reference loops.
+// The previous version (xor + popcount on the vector pipe, train descriptor as a scalar operand: 19 instructions per
+// pair of descriptors, 174 us per 256 x 1000 x 1000) is in the git history.
 // ------------------------------------------------------------------------------------------------
 #define MT_SPLIT 16     // most ways the train set is split over blockIdx.y; partials merged by k_match_merge.  The launcher picks
-                        // the smallest split that still fills the chip (every extra split repeats the query loads and
+                        // the smallest split that still fills the chip (every extra split repeats the query expansion and
                         // one partial record per query)
-#ifndef MT_WAVES
-#define MT_WAVES 1      // waves per block (independent: no LDS, no barrier)
-#endif
-#define MT_QPB (MT_WAVES * 128)   // queries per block: two per lane
-__global__ __launch_bounds__(64 * MT_WAVES) void k_match(const uint8_t *__restrict__ q, const int *__restrict__ nq,
+#define MT_WAVES 4      // waves per block; they share the train key table
+#define MT_QPW 64       // queries per wave: two MFMA column tiles
+#define MT_QPB (MT_WAVES * MT_QPW)
+#define MT_CHUNK 4096   // train descriptors per key table (12 index bits in the key)
+typedef int mt_v4i __attribute__((ext_vector_type(4)));
+typedef int mt_v16i __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ uint32_t mt_min2(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t mt_max2(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__global__ __launch_bounds__(64 * MT_WAVES, 4) void k_match(const uint8_t *__restrict__ q, const int *__restrict__ nq,
                                                          long long q_stride, const uint8_t *__restrict__ t,
                                                          const int *__restrict__ nt, long long t_stride,
-                                                         uint2 *__restrict__ partial, int out_stride, int nsplit) {
-    // key = dist << 20 | index: min(key) is the best match with the lowest index on ties; the second-smallest
-    // key carries the second-best distance (counting duplicates), exactly the bookkeeping of the reference loops.
+                                                         uint2 *__restrict__ partial, int *__restrict__ best_idx,
+                                                         int *__restrict__ best_dist, int *__restrict__ second_dist,
+                                                         int out_stride, int nsplit) {
+    __shared__ __attribute__((aligned(16))) int s_tk[MT_CHUNK];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pr = blockIdx.z, sp = blockIdx.y;
     const int NQ = min(nq[pr], out_stride), NT = min(nt[pr], 1 << 20);   // contract (orbx.h): counts beyond out_stride are ignored
-    const int qw = blockIdx.x * MT_QPB + w * 128;
-    if (qw >= NQ) return;
-    const int qi0 = qw + lane, qi1 = qi0 + 64;
-    const uint4 *qp = (const uint4 *)(q + (long long)pr * q_stride);
-    const uint4 *tp = (const uint4 *)(t + (long long)pr * t_stride);
-    uint4 qa0 = make_uint4(0, 0, 0, 0), qb0 = qa0, qa1 = qa0, qb1 = qa0;
-    if (qi0 < NQ) { qa0 = qp[2 * qi0]; qb0 = qp[2 * qi0 + 1]; }
-    if (qi1 < NQ) { qa1 = qp[2 * qi1]; qb1 = qp[2 * qi1 + 1]; }
-    const int chunk = (NT + nsplit - 1) / nsplit;
-    const int j0 = sp * chunk, j1 = min(NT, j0 + chunk);
-    uint32_t best0 = 0xffffffffu, second0 = 0xffffffffu, best1 = 0xffffffffu, second1 = 0xffffffffu;
-#pragma unroll 4
-    for (int j = j0; j < j1; ++j) {
-        const uint4 ta = tp[2 * j], tb = tp[2 * j + 1];   // wave-uniform address: scalar loads
-        const uint32_t d0 = __popc(qa0.x ^ ta.x) + __popc(qa0.y ^ ta.y) + __popc(qa0.z ^ ta.z) + __popc(qa0.w ^ ta.w) +
-                            __popc(qb0.x ^ tb.x) + __popc(qb0.y ^ tb.y) + __popc(qb0.z ^ tb.z) + __popc(qb0.w ^ tb.w);
-        const uint32_t d1 = __popc(qa1.x ^ ta.x) + __popc(qa1.y ^ ta.y) + __popc(qa1.z ^ ta.z) + __popc(qa1.w ^ ta.w) +
-                            __popc(qb1.x ^ tb.x) + __popc(qb1.y ^ tb.y) + __popc(qb1.z ^ tb.z) + __popc(qb1.w ^ tb.w);
-        const uint32_t key0 = (d0 << 20) | (uint32_t)j, key1 = (d1 << 20) | (uint32_t)j;
-        // best <= second always: the new second-smallest is the median of (best, second, key)  (one v_med3_u32)
-        second0 = max(min(best0, second0), min(max(best0, second0), key0));
-        best0 = min(best0, key0);
-        second1 = max(min(best1, second1), min(max(best1, second1), key1));
-        best1 = min(best1, key1);
+    if ((int)blockIdx.x * MT_QPB >= NQ) return;
+    const int r = lane & 31, h = lane >> 5;
+    const uint8_t *qp = q + (long long)pr * q_stride;
+    const uint8_t *tp = t + (long long)pr * t_stride;
+    // this block's share of the train set, in whole tiles of 32
+    const int per = ((NT + 31) / 32 + nsplit - 1) / nsplit * 32;
+    const int j0 = min(NT, sp * per), j1 = min(NT, j0 + per);
+    // ---- queries: lane (r, h) holds bytes 16h .. 16h+15 of query r of each tile, expanded bit plane by bit plane
+    const int qw = blockIdx.x * MT_QPB + w * MT_QPW;
+    const bool wave_on = qw < NQ;
+    mt_v4i bq[2][8];
+    int pq[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int qi = qw + 32 * c + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (qi < NQ) v = *(const uint4 *)(qp + (long long)qi * 32 + 16 * h);
+        pq[c] = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        pq[c] += __shfl_xor(pq[c], 32);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            bq[c][p][0] = (int)((v.x << (7 - p)) & 0x80808080u);
+            bq[c][p][1] = (int)((v.y << (7 - p)) & 0x80808080u);
+            bq[c][p][2] = (int)((v.z << (7 - p)) & 0x80808080u);
+            bq[c][p][3] = (int)((v.w << (7 - p)) & 0x80808080u);
+        }
     }
-    uint2 *po = partial + ((long long)pr * nsplit + sp) * out_stride;
-    if (qi0 < NQ) po[qi0] = make_uint2(best0, second0);
-    if (qi1 < NQ) po[qi1] = make_uint2(best1, second1);
+    // running result over the chunks, in the output format dist << 20 | index
+    uint32_t gbest[2] = {0xffffffffu, 0xffffffffu}, gsecond[2] = {0xffffffffu, 0xffffffffu};
+    for (int c0 = j0; c0 < j1; c0 += MT_CHUNK) {
+        const int c1 = min(j1, c0 + MT_CHUNK), n = c1 - c0, npad = (n + 31) & ~31;
+        __syncthreads();   // the previous chunk's table is no longer read
+        for (int i = threadIdx.x; i < npad; i += 64 * MT_WAVES) {
+            int key = 0x7fffffff;   // rows past the end: never the minimum (their descriptor is read as zero below)
+            if (i < n) {
+                const uint4 a = *(const uint4 *)(tp + (long long)(c0 + i) * 32), b = *(const uint4 *)(tp + (long long)(c0 + i) * 32 + 16);
+                const int pt = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+                key = ((pt + 256) << 12) | i;
+            }
+            s_tk[i] = key;
+        }
+        __syncthreads();
+        if (!wave_on) continue;
+        int best[2] = {0x7fffffff, 0x7fffffff}, second[2] = {0x7fffffff, 0x7fffffff};
+        const uint8_t *trow = tp + (long long)(c0 + r) * 32 + 16 * h;
+        uint4 ta = make_uint4(0, 0, 0, 0);
+        if (r < n) ta = *(const uint4 *)trow;
+        for (int jt = 0; jt < npad; jt += 32) {
+            const uint4 tc = ta;
+            // next tile's descriptors requested before this tile's MFMAs
+            ta = make_uint4(0, 0, 0, 0);
+            if (jt + 32 + r < n) ta = *(const uint4 *)(trow + (long long)(jt + 32) * 32);
+            mt_v16i acc0, acc1;
+            {
+                const int4 *kp = (const int4 *)(s_tk + jt + 4 * h);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int4 k4 = kp[2 * g];   // rows 8g + 4h .. + 3 of the tile = registers 4g .. 4g+3
+                    acc0[4 * g] = k4.x; acc0[4 * g + 1] = k4.y; acc0[4 * g + 2] = k4.z; acc0[4 * g + 3] = k4.w;
+                }
+                acc1 = acc0;
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                mt_v4i a;
+                if (p < 6) {
+                    a[0] = (int)((tc.x << (6 - p)) & 0x40404040u); a[1] = (int)((tc.y << (6 - p)) & 0x40404040u);
+                    a[2] = (int)((tc.z << (6 - p)) & 0x40404040u); a[3] = (int)((tc.w << (6 - p)) & 0x40404040u);
+                } else if (p == 6) {
+                    a[0] = (int)(tc.x & 0x40404040u); a[1] = (int)(tc.y & 0x40404040u);
+                    a[2] = (int)(tc.z & 0x40404040u); a[3] = (int)(tc.w & 0x40404040u);
+                } else {
+                    a[0] = (int)((tc.x >> 1) & 0x40404040u); a[1] = (int)((tc.y >> 1) & 0x40404040u);
+                    a[2] = (int)((tc.z >> 1) & 0x40404040u); a[3] = (int)((tc.w >> 1) & 0x40404040u);
+                }
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][p], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][p], acc1, 0, 0, 0);
+            }
+            // best <= second always: the new second-smallest is the median of (best, second, key)  (one v_med3_i32)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k0 = acc0[i], k1 = acc1[i];
+                second[0] = max(min(best[0], second[0]), min(max(best[0], second[0]), k0));
+                best[0] = min(best[0], k0);
+                second[1] = max(min(best[1], second[1]), min(max(best[1], second[1]), k1));
+                best[1] = min(best[1], k1);
+            }
+        }
+        // fold the chunk into the running result
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t b = best[c] == 0x7fffffff ? 0xffffffffu
+                                                     : ((uint32_t)((best[c] >> 12) + pq[c] - 256) << 20) | (uint32_t)(c0 + (best[c] & 4095));
+            const uint32_t s2 = second[c] == 0x7fffffff ? 0xffffffffu
+                                                        : ((uint32_t)((second[c] >> 12) + pq[c] - 256) << 20) | (uint32_t)(c0 + (second[c] & 4095));
+            gsecond[c] = mt_min2(mt_min2(gsecond[c], s2), mt_max2(gbest[c], b));
+            gbest[c] = mt_min2(gbest[c], b);
+        }
+    }
+    if (!wave_on) return;
+    // the two lane halves hold different train rows of the same query
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const uint32_t ob = (uint32_t)__shfl_xor((int)gbest[c], 32), os = (uint32_t)__shfl_xor((int)gsecond[c], 32);
+        const uint32_t second = mt_min2(mt_min2(gsecond[c], os), mt_max2(gbest[c], ob));
+        const uint32_t best = mt_min2(gbest[c], ob);
+        const int qi = qw + 32 * c + r;
+        if (h == 0 && qi < NQ) {
+            if (nsplit > 1) {
+                partial[((long long)pr * nsplit + sp) * out_stride + qi] = make_uint2(best, second);
+            } else {
+                const long long o = (long long)pr * out_stride + qi;
+                best_idx[o] = best == 0xffffffffu ? -1 : (int)(best & 0xfffffu);
+                best_dist[o] = best == 0xffffffffu ? 0x7fffffff : (int)(best >> 20);
+                second_dist[o] = second == 0xffffffffu ? 0x7fffffff : (int)(second >> 20);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_match_merge(const int *__restrict__ nq, const uint2 *__restrict__ partial,
@@ -2215,16 +2323,17 @@ void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, 
                        const uint8_t *t, const int *nt, long long t_stride, int *best_idx, int *best_dist,
                        int *second_dist, int out_stride, void *workspace) {
     if (npairs <= 0 || max_nq <= 0) return;
-    // target waves per launch (a few rounds of the chip's 8192 wave slots), then the split that reaches it
+    // target waves per launch (the chip holds 4096 waves of this kernel at once), then the split that reaches it
     static int target = -1;
-    if (target < 0) { const char *e = getenv("ORBX_MATCH_WAVES"); target = e ? atoi(e) : 16384; }
+    if (target < 0) { const char *e = getenv("ORBX_MATCH_WAVES"); target = e ? atoi(e) : 4096; }
     const int qblocks = (max_nq + MT_QPB - 1) / MT_QPB;
-    const long long base = (long long)qblocks * npairs * MT_WAVES;
-    const int nsplit = (int)std::min<long long>(MT_SPLIT, std::max<long long>(1, (target + base - 1) / base));
+    const long long base = (long long)((max_nq + MT_QPW - 1) / MT_QPW) * npairs;
+    const int nsplit = (int)std::min<long long>(MT_SPLIT, std::max<long long>(1, target / base));
     hipLaunchKernelGGL(k_match, dim3(qblocks, nsplit, npairs), dim3(64 * MT_WAVES), 0, s, q, nq,
-                       q_stride, t, nt, t_stride, (uint2 *)workspace, out_stride, nsplit);
-    hipLaunchKernelGGL(k_match_merge, dim3((max_nq + 255) / 256, npairs), dim3(256), 0, s, nq, (const uint2 *)workspace,
-                       best_idx, best_dist, second_dist, out_stride, nsplit);
+                       q_stride, t, nt, t_stride, (uint2 *)workspace, best_idx, best_dist, second_dist, out_stride, nsplit);
+    if (nsplit > 1)
+        hipLaunchKernelGGL(k_match_merge, dim3((max_nq + 255) / 256, npairs), dim3(256), 0, s, nq, (const uint2 *)workspace,
+                           best_idx, best_dist, second_dist, out_stride, nsplit);
 }
 void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *dist) {
     const long long n = (long long)nq * nt;

@@ -208,12 +208,15 @@ def test_match_bruteforce_random_ties_empty():
     rng = np.random.default_rng(3)
     ex = ORBextractor(300)
     m = ORBmatcher(0.9, True, extractor=ex)
-    for nq, nt in [(1, 1), (63, 64), (64, 257), (65, 255), (1000, 1003), (300, 0)]:
+    # (5, 4097) / (257, 8200): more train descriptors than one key table of the kernel holds (4096)
+    for nq, nt in [(1, 1), (63, 64), (64, 257), (65, 255), (1000, 1003), (300, 0), (5, 4097), (257, 8200), (33, 31)]:
         q = rng.integers(0, 256, (nq, 32)).astype(np.uint8)
         t = rng.integers(0, 256, (nt, 32)).astype(np.uint8)
         if nt > 50:
             t[7] = t[33] = q[0]                            # ties: first index wins, second == best
             q[1] = t[nt - 1]
+            q[2] = 0; t[40] = 255; t[41] = 0               # distances 256 and 0, popcounts 0 and 256
+            q[3] = 255
         got = m.match_bruteforce(q, t)
         exp = oracle.match_bruteforce(q, t)
         for a, b, name in zip(got, exp, ("idx", "best", "second")):
@@ -222,6 +225,35 @@ def test_match_bruteforce_random_ties_empty():
     D = m.distance_matrix(q, t)
     assert np.array_equal(D, np.unpackbits(q[:, None] ^ t[None], axis=2).sum(axis=2))
     assert m.DescriptorDistance(q[0], t[0]) == oracle.descriptor_distance(q[0], t[0])
+
+
+def test_match_batch_device_ragged_pairs():
+    """orbx_match_bruteforce_device over several independent (query, train) sets of different sizes in one call: empty
+    sets, counts that are no multiple of the kernel's 32 x 32 tiles, a count beyond out_stride (ignored, nothing written
+    outside the pair's output row), and enough pairs that the launcher does not split the train sets"""
+    import torch
+    from orb_slam2_detailed_comments_amd import _capi
+    rng = np.random.default_rng(11)
+    L = _capi.lib()
+    ex = ORBextractor(300)
+    for npairs, cap_q, cap_t in [(7, 200, 300), (40, 130, 70)]:
+        nq = rng.integers(0, cap_q + 1, npairs).astype(np.int32); nt = rng.integers(0, cap_t + 1, npairs).astype(np.int32)
+        nq[0] = cap_q + 50; nt[1] = 0; nq[2] = 0; nq[3] = 33; nt[3] = 31
+        q = rng.integers(0, 256, (npairs, cap_q + 50, 32)).astype(np.uint8); t = rng.integers(0, 256, (npairs, cap_t, 32)).astype(np.uint8)
+        dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+        dnq, dnt = torch.from_numpy(nq).cuda(), torch.from_numpy(nt).cuda()
+        out = [torch.full((npairs, cap_q), -7, dtype=torch.int32, device="cuda") for _ in range(3)]
+        torch.cuda.synchronize()
+        _capi.check(L.orbx_match_bruteforce_device(ex.handle, npairs, _capi.ptr(dq), _capi.ptr(dnq), (cap_q + 50) * 32, _capi.ptr(dt),
+                                                   _capi.ptr(dnt), cap_t * 32, _capi.ptr(out[0]), _capi.ptr(out[1]), _capi.ptr(out[2]), cap_q))
+        ex.synchronize()
+        got = [o.cpu().numpy() for o in out]
+        for p in range(npairs):
+            n = min(int(nq[p]), cap_q)
+            exp = oracle.match_bruteforce(q[p, :n], t[p, :nt[p]])
+            for a, b, name in zip(got, exp, ("idx", "best", "second")):
+                assert np.array_equal(a[p, :n], b), f"{name} pair {p} nq={nq[p]} nt={nt[p]}"
+                assert (a[p, n:] == -7).all(), f"{name} pair {p}: written beyond the pair's query count"
 
 
 def test_match_consecutive_frames_and_ratio():
