@@ -1457,8 +1457,10 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
 //     (dist, index) for the lane's query -- and the bookkeeping is two instructions per distance: second =
 //     med3(key, best, second), best = min(best, key).  min(key) is the best match with the lowest index on ties and the
 //     second-smallest key carries the second-best distance counting duplicates, exactly the reference loops.
-// The previous version (xor + popcount on the vector pipe, train descriptor as a scalar operand: 19 instructions per
-// pair of descriptors, 174 us per 256 x 1000 x 1000) is in the git history.
+// 174 -> 60-65 us per 256 x 1000 x 1000 against k_match_valu below (xor + popcount on the vector pipe), which north_star
+// names as the form of this kernel ("no MFMA -- this is integer/bitwise work"): the premise does not hold for the matcher
+// -- the result is the same integer, bit for bit -- so the MFMA kernel is the default and the vector-pipe kernel stays
+// selectable (ORBX_MATCH_KERNEL=valu) and parity-tested, for A/B runs and for readers who want the path as specified.
 // ------------------------------------------------------------------------------------------------
 #define MT_SPLIT 16     // most ways the train set is split over blockIdx.y; partials merged by k_match_merge.  The launcher picks
                         // the smallest split that still fills the chip (every extra split repeats the query expansion and
@@ -1598,6 +1600,48 @@ __global__ __launch_bounds__(64 * MT_WAVES, 4) void k_match(const uint8_t *__res
             }
         }
     }
+}
+
+// The same bookkeeping on the vector pipe (the round-1 kernel, ORBX_MATCH_KERNEL=valu): two queries per lane (16 dwords in
+// VGPRs); the train descriptor of an iteration is the same for the whole wave, so it is fetched with SCALAR loads
+// (s_load_dwordx8 through the scalar cache) and used as the SGPR operand of v_xor: no LDS staging, no barrier.  19 vector
+// instructions per pair of distances; partial results always go through k_match_merge.
+__global__ __launch_bounds__(64) void k_match_valu(const uint8_t *__restrict__ q, const int *__restrict__ nq,
+                                                         long long q_stride, const uint8_t *__restrict__ t,
+                                                         const int *__restrict__ nt, long long t_stride,
+                                                         uint2 *__restrict__ partial, int out_stride, int nsplit) {
+    // key = dist << 20 | index: min(key) is the best match with the lowest index on ties; the second-smallest
+    // key carries the second-best distance (counting duplicates), exactly the bookkeeping of the reference loops.
+    const int lane = threadIdx.x, pr = blockIdx.z, sp = blockIdx.y;
+    const int NQ = min(nq[pr], out_stride), NT = min(nt[pr], 1 << 20);   // contract (orbx.h): counts beyond out_stride are ignored
+    const int qw = blockIdx.x * 128;
+    if (qw >= NQ) return;
+    const int qi0 = qw + lane, qi1 = qi0 + 64;
+    const uint4 *qp = (const uint4 *)(q + (long long)pr * q_stride);
+    const uint4 *tp = (const uint4 *)(t + (long long)pr * t_stride);
+    uint4 qa0 = make_uint4(0, 0, 0, 0), qb0 = qa0, qa1 = qa0, qb1 = qa0;
+    if (qi0 < NQ) { qa0 = qp[2 * qi0]; qb0 = qp[2 * qi0 + 1]; }
+    if (qi1 < NQ) { qa1 = qp[2 * qi1]; qb1 = qp[2 * qi1 + 1]; }
+    const int chunk = (NT + nsplit - 1) / nsplit;
+    const int j0 = sp * chunk, j1 = min(NT, j0 + chunk);
+    uint32_t best0 = 0xffffffffu, second0 = 0xffffffffu, best1 = 0xffffffffu, second1 = 0xffffffffu;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const uint4 ta = tp[2 * j], tb = tp[2 * j + 1];   // wave-uniform address: scalar loads
+        const uint32_t d0 = __popc(qa0.x ^ ta.x) + __popc(qa0.y ^ ta.y) + __popc(qa0.z ^ ta.z) + __popc(qa0.w ^ ta.w) +
+                            __popc(qb0.x ^ tb.x) + __popc(qb0.y ^ tb.y) + __popc(qb0.z ^ tb.z) + __popc(qb0.w ^ tb.w);
+        const uint32_t d1 = __popc(qa1.x ^ ta.x) + __popc(qa1.y ^ ta.y) + __popc(qa1.z ^ ta.z) + __popc(qa1.w ^ ta.w) +
+                            __popc(qb1.x ^ tb.x) + __popc(qb1.y ^ tb.y) + __popc(qb1.z ^ tb.z) + __popc(qb1.w ^ tb.w);
+        const uint32_t key0 = (d0 << 20) | (uint32_t)j, key1 = (d1 << 20) | (uint32_t)j;
+        // best <= second always: the new second-smallest is the median of (best, second, key)  (one v_med3_u32)
+        second0 = max(min(best0, second0), min(max(best0, second0), key0));
+        best0 = min(best0, key0);
+        second1 = max(min(best1, second1), min(max(best1, second1), key1));
+        best1 = min(best1, key1);
+    }
+    uint2 *po = partial + ((long long)pr * nsplit + sp) * out_stride;
+    if (qi0 < NQ) po[qi0] = make_uint2(best0, second0);
+    if (qi1 < NQ) po[qi1] = make_uint2(best1, second1);
 }
 
 __global__ __launch_bounds__(256) void k_match_merge(const int *__restrict__ nq, const uint2 *__restrict__ partial,
@@ -2132,6 +2176,7 @@ __global__ void k_clear(int *a, int na, int *b, int nb, int *c, int nc) {
 #include "orbx_launch.h"
 #include <string>
 #include <cstdio>
+#include <cstring>
 #include <mutex>
 
 hipError_t orbx_upload_pattern() {
@@ -2323,6 +2368,17 @@ void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, 
                        const uint8_t *t, const int *nt, long long t_stride, int *best_idx, int *best_dist,
                        int *second_dist, int out_stride, void *workspace) {
     if (npairs <= 0 || max_nq <= 0) return;
+    const char *kind = getenv("ORBX_MATCH_KERNEL");   // read per launch: the parity tests run both kernels in one process
+    if (kind && !strcmp(kind, "valu")) {
+        const int qblocks = (max_nq + 127) / 128;
+        const long long base = (long long)qblocks * npairs;
+        const int nsplit = (int)std::min<long long>(MT_SPLIT, std::max<long long>(1, (16384 + base - 1) / base));
+        hipLaunchKernelGGL(k_match_valu, dim3(qblocks, nsplit, npairs), dim3(64), 0, s, q, nq, q_stride, t, nt, t_stride,
+                           (uint2 *)workspace, out_stride, nsplit);
+        hipLaunchKernelGGL(k_match_merge, dim3((max_nq + 255) / 256, npairs), dim3(256), 0, s, nq, (const uint2 *)workspace,
+                           best_idx, best_dist, second_dist, out_stride, nsplit);
+        return;
+    }
     // target waves per launch (the chip holds 4096 waves of this kernel at once), then the split that reaches it
     static int target = -1;
     if (target < 0) { const char *e = getenv("ORBX_MATCH_WAVES"); target = e ? atoi(e) : 4096; }

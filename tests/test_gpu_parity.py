@@ -204,7 +204,18 @@ def test_full_batch_of_baseline_config():
 
 
 # ---------------------------------------------------------------------------------------- matching
-def test_match_bruteforce_random_ties_empty():
+@pytest.fixture(params=["mfma", "valu"])
+def match_kernel(request, monkeypatch):
+    """both Hamming kernels of the library: the matrix-core one (default) and the xor + popcount one (ORBX_MATCH_KERNEL=valu,
+    read by the launcher at every launch)"""
+    if request.param == "valu":
+        monkeypatch.setenv("ORBX_MATCH_KERNEL", "valu")
+    else:
+        monkeypatch.delenv("ORBX_MATCH_KERNEL", raising=False)
+    return request.param
+
+
+def test_match_bruteforce_random_ties_empty(match_kernel):
     rng = np.random.default_rng(3)
     ex = ORBextractor(300)
     m = ORBmatcher(0.9, True, extractor=ex)
@@ -227,7 +238,7 @@ def test_match_bruteforce_random_ties_empty():
     assert m.DescriptorDistance(q[0], t[0]) == oracle.descriptor_distance(q[0], t[0])
 
 
-def test_match_batch_device_ragged_pairs():
+def test_match_batch_device_ragged_pairs(match_kernel):
     """orbx_match_bruteforce_device over several independent (query, train) sets of different sizes in one call: empty
     sets, counts that are no multiple of the kernel's 32 x 32 tiles, a count beyond out_stride (ignored, nothing written
     outside the pair's output row), and enough pairs that the launcher does not split the train sets"""
