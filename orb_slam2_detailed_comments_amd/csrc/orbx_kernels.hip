@@ -1457,6 +1457,10 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
 //     (dist, index) for the lane's query -- and the bookkeeping is two instructions per distance: second =
 //     med3(key, best, second), best = min(best, key).  min(key) is the best match with the lowest index on ties and the
 //     second-smallest key carries the second-best distance counting duplicates, exactly the reference loops.
+// Measured on 256 x 1000 x 1000 (tools/match_rate.py): 60 us; without the bookkeeping 48 us, without the expansion of the
+// train tiles 56 us, MFMAs + loads alone 49 us (= 2.7 Pop/s: the matrix pipe at the clock the chip holds under this load).
+// The same kernel on v_mfma_i32_16x16x64_i8 (four 16-column query tiles per wave, K step = two bit planes) is bit-exact
+// and slower, 71 us: twice the operand traffic per product and rotates instead of shifts in the expansion.
 // 174 -> 60-65 us per 256 x 1000 x 1000 against k_match_valu below (xor + popcount on the vector pipe), which north_star
 // names as the form of this kernel ("no MFMA -- this is integer/bitwise work"): the premise does not hold for the matcher
 // -- the result is the same integer, bit for bit -- so the MFMA kernel is the default and the vector-pipe kernel stays
