@@ -350,6 +350,15 @@ def main():
             # with several pipelines, or the forked launch sequence, per-kernel durations include time shared with other kernels
             "kernel_ms_overlapped": NS > 1 or int(os.environ.get("ORBX_FORK_LEVEL", "0")) > 0 or (stereo and args.stereo_streams == 2),
         }
+        if not stereo and prof["k_match"][0] > 0 and os.environ.get("ORBX_MATCH_KERNEL") != "valu":
+            # the one GEMM-shaped kernel of the path: brute-force Hamming as v_mfma_i32_32x32x32_i8 (dist = |q| + |t| - 2 q.t);
+            # 2 operations per (query bit, train bit) pair against the dense int8 peak (2 x the 2.5 PFLOP/s bf16 peak).
+            # Duration: HIP events of the calibration pass (every kernel alone on its stream).
+            m_us = prof["k_match"][0] / 2 * 1e3          # per step: one launch (plus the merge kernel for small batches)
+            m_ops = 2.0 * B * n_kp * n_kp * 256
+            out["roofline_mfma"] = {"bound": "mfma", "kernel": "k_match", "achieved": round(m_ops / (m_us * 1e-6) / 1e12, 1),
+                                    "peak": 5000.0, "unit": "TOP/s", "frac": round(m_ops / (m_us * 1e-6) / 1e12 / 5000.0, 4),
+                                    "avg_launch_us": round(m_us, 2)}
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only (the other ranks would idle through it)
             cfps, nsample, pinned = cpu_baseline(frames, right, NF, stereo, mb, mbf)
             out["cpu_baseline"] = {"value": round(cfps, 2), "unit": "frames/s", "cores": 1, "kind": "port",
