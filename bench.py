@@ -150,6 +150,10 @@ def main():
     ap.add_argument("--stereo-streams", type=int, default=1, choices=(1, 2),
                     help="stereo configs: 1 = both eyes' extractions on one stream (kernels run alone, durations are their own); "
                          "2 = one stream per eye, as the reference's two extraction threads (overlapped durations)")
+    ap.add_argument("--stereo-batch", default="merged", choices=("merged", "split"),
+                    help="stereo configs: merged = both eyes of a step through ONE extractor batch of 2 x batch images (left images "
+                         "first; orbx_stereo_match_batch_device with hl == hr); split = one handle and one batch per eye, as the "
+                         "reference's two ORBextractor objects")
     ap.add_argument("--gather", default="gather", choices=("gather", "all_gather"),
                     help="collective for the per-frame keypoint records: to rank 0 (default) or to every rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -189,15 +193,17 @@ def main():
     d_right = torch.from_numpy(right).to(dev) if stereo else None
     # NS independent pipelines (handle + HIP stream + result buffers), used round-robin: while one batch is in its
     # latency-bound tail (quadtree, small pyramid levels) the next batch's streaming kernels fill the chip.
-    exs = [ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B, device=local_rank) for _ in range(NS)]
-    exR = ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B, device=local_rank) if stereo else None
+    merged = stereo and args.stereo_batch == "merged" and args.stereo_streams == 1
+    exs = [ORBextractor(NF, 1.2, 8, 20, 7, max_batch=2 * B if merged else B, device=local_rank) for _ in range(NS)]
+    exR = ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B, device=local_rank) if stereo and not merged else None
+    d_both = torch.cat([d_imgs, d_right]) if merged else None
     ex = exs[0]
     cap = ex.max_keypoints(W, H)
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     for e, st in zip(exs, streams):
         e.set_stream(st.cuda_stream)
     stream_r = None
-    if stereo:   # the reference extracts the two eyes on two threads (src/Frame.cc:158-168): two handles; --stereo-streams 2 gives each its own stream
+    if stereo and not merged:   # the reference extracts the two eyes on two threads (src/Frame.cc:158-168): two handles; --stereo-streams 2 gives each its own stream
         stream_r = torch.cuda.Stream(device=dev) if args.stereo_streams == 2 else streams[0]
         exR.set_stream(stream_r.cuda_stream)
     # slot 0 of the result buffers carries the last frame of the previous step (match t vs t-1)
@@ -217,6 +223,10 @@ def main():
                      countsR=torch.zeros(B, dtype=torch.int32, device=dev), statusR=torch.zeros(B, dtype=torch.int32, device=dev),
                      uright=torch.zeros((B, cap), dtype=torch.float32, device=dev), depth=torch.zeros((B, cap), dtype=torch.float32, device=dev),
                      nmatch=torch.zeros(B, dtype=torch.int32, device=dev))
+        if merged:   # one batch of 2B images: left eyes in [0, B), right eyes in [B, 2B)
+            b.update(kpsM=torch.zeros((2 * B, cap * 28), dtype=torch.uint8, device=dev),
+                     descM=torch.zeros((2 * B, cap * 32), dtype=torch.uint8, device=dev),
+                     countsM=torch.zeros(2 * B, dtype=torch.int32, device=dev), statusM=torch.zeros(2 * B, dtype=torch.int32, device=dev))
         bufs.append(b)
     # slot 0 of a pipeline's buffers = descriptors + count of the last frame of the PREVIOUS step (the train set of pair 0):
     # written by that step, after its own match, straight into the buffers of the pipeline that runs the next step
@@ -230,8 +240,17 @@ def main():
         k = i % NS
         e, st, b = exs[k], streams[k], bufs[k]
         with torch.cuda.stream(st):
-            e.extract_batch_device(d_imgs, B, W, H, W, W * H, b["kps"][1:], b["desc"][1:], b["counts"][1:], b["status"], cap)
-            if stereo:
+            if merged:
+                e.extract_batch_device(d_both, 2 * B, W, H, W, W * H, b["kpsM"], b["descM"], b["countsM"], b["statusM"], cap)
+                _capi.check(L.orbx_stereo_match_batch_device(
+                    e.handle, e.handle, B, _capi.ptr(b["kpsM"][:B]), _capi.ptr(b["descM"][:B]), _capi.ptr(b["countsM"][:B]),
+                    _capi.ptr(b["kpsM"][B:]), _capi.ptr(b["descM"][B:]), _capi.ptr(b["countsM"][B:]), cap, mb, mbf,
+                    _capi.ptr(b["uright"]), _capi.ptr(b["depth"]), _capi.ptr(b["nmatch"])))
+            else:
+                e.extract_batch_device(d_imgs, B, W, H, W, W * H, b["kps"][1:], b["desc"][1:], b["counts"][1:], b["status"], cap)
+            if merged:
+                pass
+            elif stereo:
                 with torch.cuda.stream(stream_r):
                     exR.extract_batch_device(d_right, B, W, H, W, W * H, b["kpsR"], b["descR"], b["countsR"], b["statusR"], cap)
                 _capi.check(L.orbx_stereo_match_batch_device(
@@ -249,17 +268,21 @@ def main():
                 if NS > 1:
                     carry_ready.record(st)
             if gatherer is not None:
-                gatherer.gather(b["counts"][1:], b["kps"][1:], b["desc"][1:], async_op=True)
+                if merged:
+                    gatherer.gather(b["countsM"][:B], b["kpsM"][:B], b["descM"][:B], async_op=True)
+                else:
+                    gatherer.gather(b["counts"][1:], b["kps"][1:], b["desc"][1:], async_op=True)
 
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize(dev)
-    status = torch.stack([b["status"] for b in bufs] + ([bufs[0]["statusR"]] if stereo else [])).cpu().numpy()
+    status = (bufs[0]["statusM"] if merged else
+              torch.stack([b["status"] for b in bufs] + ([bufs[0]["statusR"]] if stereo else []))).cpu().numpy()
     if status.any():
         raise SystemExit(f"extraction reported status {status.tolist()}")
-    counts = bufs[0]["counts"][1:].cpu().numpy()
+    counts = (bufs[0]["countsM"] if merged else bufs[0]["counts"][1:]).cpu().numpy()
     n_kp = float(counts.mean())
-    handles = exs + ([exR] if stereo else [])
+    handles = exs + ([exR] if exR is not None else [])
 
     # calibration pass: which kernel dominates?  (all kernels timed with HIP events on the launch stream)
     for e in handles:
@@ -323,6 +346,7 @@ def main():
             args.config if (W, H, NF) == (640, 480, 1000) else "", f"frames/sec ORB extract+match ({NF} kp, {W}x{H}{', stereo' if stereo else ''})")
         kind = (f"synthetic {W}x{H} stereo stream (stereo frame = left + right image, both extracted), nFeatures={NF}, 8 levels, "
                 f"scale 1.2, FAST 20/7, extract x2 + ComputeStereoMatches, batch {B} stereo frames/GPU resident in HBM"
+                + (f", both eyes through one extractor batch of {2 * B} images" if merged else ", one extractor batch per eye")
                 if stereo else
                 f"synthetic {W}x{H} mono stream, nFeatures={NF}, 8 levels, scale 1.2, FAST 20/7, "
                 f"extract+match(t vs t-1), batch {B} frames/GPU resident in HBM, {NS} pipelines/GPU")

@@ -171,7 +171,9 @@ orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int frame_left, 
 /* Batched, device-resident form: pair p = frame p of the last orbx_extract_batch_device of `hl` (left eyes) and of `hr`
  * (right eyes); d_k* / d_d* / d_n* are the device buffers those calls filled, `cap` records apart.  Outputs (device):
  * u_right / depth [npairs][cap], nmatches [npairs].  The median cut of :1160-1175 runs on the device too.  Asynchronous on
- * hl's stream. */
+ * hl's stream.  hl == hr is allowed: the two eyes then went through ONE orbx_extract_batch_device call of 2 * npairs images
+ * on that handle, left images first (frames 0 .. npairs-1), right images after them (the reference's two extractors carry the
+ * same parameters in stereo, src/Tracking.cc; one batch halves the launches per stereo frame). */
 orbx_status orbx_stereo_match_batch_device(orbx_handle *hl, orbx_handle *hr, int npairs, const orbx_keypoint *d_kl,
                                            const uint8_t *d_dl, const int32_t *d_nl, const orbx_keypoint *d_kr,
                                            const uint8_t *d_dr, const int32_t *d_nr, int cap, float mb, float mbf,

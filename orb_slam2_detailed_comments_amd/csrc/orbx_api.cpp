@@ -1304,7 +1304,10 @@ extern "C" orbx_status orbx_stereo_match_batch_device(orbx_handle *hl, orbx_hand
     if (npairs <= 0 || cap <= 0 || cap > 65535 || !d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_u_right || !d_depth ||
         !d_nmatches || !(mb > 0.f))
         return fail(ORBX_BAD_ARGUMENT, "bad argument");
-    orbx_status st = check_level(hl, npairs - 1, 0);
+    // hl == hr: both eyes went through ONE batch of 2 * npairs images (left images first): the right pyramids are frames
+    // npairs .. 2 npairs - 1 of that handle (half as many launches per stereo frame as two handles need)
+    const bool one_batch = hl == hr;
+    orbx_status st = check_level(hl, (one_batch ? 2 * npairs : npairs) - 1, 0);
     if (st != ORBX_OK) return st;
     st = check_level(hr, npairs - 1, 0);
     if (st != ORBX_OK) return st;
@@ -1335,7 +1338,8 @@ extern "C" orbx_status orbx_stereo_match_batch_device(orbx_handle *hl, orbx_hand
     int *drow = scratch_take<int>(hl, (size_t)npairs * (sg.nrows0 + 1));
     uint16_t *ditems = scratch_take<uint16_t>(hl, (size_t)npairs * ipp);
     { ProfScope ps(hl, ORBX_K_MATCH);
-      orbx_launch_stereo_batch(hl->stream, sg, npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, hl->d_pyr, hr->d_pyr,
+      orbx_launch_stereo_batch(hl->stream, sg, npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, hl->d_pyr,
+                               hr->d_pyr + (one_batch ? (size_t)npairs * (size_t)hl->geom.pyr_bytes : 0),
                                (long long)hl->geom.pyr_bytes, d_u_right, d_depth, dsad, d_nmatches, drow, ditems); }
     if (two_streams) {   // ... and whatever the right stream does next (the next pair's pyramids) waits for the match that reads this one's
         HIPCHK(hipEventRecord(hl->ev_stereo, hl->stream));

@@ -174,6 +174,45 @@ def test_compute_stereo_matches_batched_device_path():
         assert np.array_equal(dep[p, :nl].cpu().numpy().view(np.uint32), od.view(np.uint32))
 
 
+def test_compute_stereo_matches_one_batch_for_both_eyes():
+    """orbx_stereo_match_batch_device with hl == hr: both eyes of B pairs went through ONE extractor batch of 2B images (left
+    images first); the right pyramids are frames B .. 2B-1 of that handle.  Against the oracle pair by pair, as the two-handle
+    form above."""
+    import torch
+    from orb_slam2_detailed_comments_amd import _capi
+    w, h, nf, B, mb, mbf = 752, 480, 1200, 3, 0.11, 47.9
+    pairs = [synth.stereo_pair(w, h, stream_id=53 + i) for i in range(B)]
+    dev = torch.device("cuda", 0)
+    ex = ORBextractor(nf, max_batch=2 * B)
+    cap = ex.max_keypoints(w, h)
+    kps = torch.zeros((2 * B, cap * 28), dtype=torch.uint8, device=dev); desc = torch.zeros((2 * B, cap * 32), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(2 * B, dtype=torch.int32, device=dev); st = torch.zeros(2 * B, dtype=torch.int32, device=dev)
+    imgs = torch.from_numpy(np.stack([p[0] for p in pairs] + [p[1] for p in pairs])).to(dev)
+    ur = torch.zeros((B, cap), dtype=torch.float32, device=dev); dep = torch.zeros_like(ur)
+    nm = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()   # fills ran on torch's stream; the handle's stream is not ordered with it
+    ex.extract_batch_device(imgs, 2 * B, w, h, w, w * h, kps, desc, cnt, st, cap)
+    L = _capi.lib()
+    _capi.check(L.orbx_stereo_match_batch_device(ex.handle, ex.handle, B, _capi.ptr(kps[:B]), _capi.ptr(desc[:B]), _capi.ptr(cnt[:B]),
+                                                 _capi.ptr(kps[B:]), _capi.ptr(desc[B:]), _capi.ptr(cnt[B:]), cap, mb, mbf,
+                                                 _capi.ptr(ur), _capi.ptr(dep), _capi.ptr(nm)))
+    ex.synchronize()
+    assert not st.cpu().numpy().any()
+    for p in range(B):
+        nl, nr = int(cnt[p]), int(cnt[B + p])
+        kL = np.frombuffer(kps[p].cpu().numpy().tobytes(), _capi.KP_DTYPE)[:nl]
+        kR = np.frombuffer(kps[B + p].cpu().numpy().tobytes(), _capi.KP_DTYPE)[:nr]
+        dL = desc[p].cpu().numpy().reshape(-1, 32)[:nl]; dR = desc[B + p].cpu().numpy().reshape(-1, 32)[:nr]
+        pyrL = [ex.pyramid_level(l, p) for l in range(8)]; pyrR = [ex.pyramid_level(l, B + p) for l in range(8)]
+        on, ou, od = oracle.stereo_matches(kL, dL, kR, dR, ex.GetScaleFactors(), ex.GetInverseScaleFactors(), pyrL, pyrR, mb, mbf)
+        assert int(nm[p]) == on and on > 20
+        assert np.array_equal(ur[p, :nl].cpu().numpy().view(np.uint32), ou.view(np.uint32))
+        assert np.array_equal(dep[p, :nl].cpu().numpy().view(np.uint32), od.view(np.uint32))
+    # more pairs than half the resident batch: refused, nothing is read past the handle's pyramids
+    assert L.orbx_stereo_match_batch_device(ex.handle, ex.handle, 2 * B, _capi.ptr(kps), _capi.ptr(desc), _capi.ptr(cnt), _capi.ptr(kps),
+                                            _capi.ptr(desc), _capi.ptr(cnt), cap, mb, mbf, _capi.ptr(ur), _capi.ptr(dep), _capi.ptr(nm)) != 0
+
+
 @pytest.mark.gpu
 def test_randomised_policy_soak():
     """tools/soak_policies.py for 15 s: ComputeStereoMatches on random stereo geometries, brute-force best / second best and the
