@@ -1869,50 +1869,56 @@ __global__ __launch_bounds__(1024) void k_stereo_rows(OrbxStereoGeom sg, const o
 // Median cut of Frame::ComputeStereoMatches (src/Frame.cc:1160-1175) on the device, one workgroup per pair: the reference
 // sorts (SAD, index) and drops everything with SAD >= 1.5f * 1.4f * median, median = element size/2 of the sorted list.
 // Only the VALUE of that element matters: two 256-bin histogram passes over the 16-bit SAD (<= 121 * 510) select it.
+// (the two selections over the 256 bins are block-wide prefix sums -- one wave scan + four wave totals -- not a serial walk by
+// one thread: 21 -> 6 us per 64 KITTI pairs)
 __global__ __launch_bounds__(256) void k_stereo_cut(const int *__restrict__ nL, int cap, const int *__restrict__ sad,
                                                     float *__restrict__ uRight, float *__restrict__ depth,
                                                     int *__restrict__ nmatches) {
     __shared__ int hist[256];
+    __shared__ int wsum[4];
     __shared__ int s_sel, s_rank, s_kept;
     const long long p = blockIdx.x;
-    const int n = min(nL[p], cap), t = threadIdx.x;
+    const int n = min(nL[p], cap), t = threadIdx.x, wv = t >> 6;
     const int *sd = sad + p * cap;
     float *ur = uRight + p * cap, *dp = depth + p * cap;
     hist[t] = 0;
-    if (t == 0) s_kept = 0;
+    if (t == 0) { s_kept = 0; s_sel = -1; s_rank = 0; }
     __syncthreads();
     for (int i = t; i < n; i += 256) { const int v = sd[i]; if (v >= 0) atomicAdd(&hist[(v >> 8) & 255], 1); }
     __syncthreads();
-    if (t == 0) {
-        int cnt = 0;
-        for (int b = 0; b < 256; ++b) cnt += hist[b];
-        s_sel = -1; s_rank = 0;
-        if (cnt > 0) {
-            int k = cnt / 2, acc = 0;
-            for (int b = 0; b < 256; ++b) { if (k < acc + hist[b]) { s_sel = b; s_rank = k - acc; break; } acc += hist[b]; }
-        }
-        s_kept = cnt;
+    // bin that holds the element of rank k = count / 2 (nth_element semantics of :1160-1165), and the rank inside it
+    int v = hist[t];
+    int incl = orbx_wave_scan(v);
+    if ((t & 63) == 63) wsum[wv] = incl;
+    __syncthreads();
+    const int cnt = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    for (int i = 0; i < wv; ++i) incl += wsum[i];
+    if (cnt > 0) {
+        const int k = cnt / 2;
+        if (incl - v <= k && k < incl) { s_sel = t; s_rank = k - (incl - v); }
     }
+    if (t == 0) s_kept = cnt;
     __syncthreads();
     const int hi = s_sel, rank = s_rank;
     if (hi < 0) { if (t == 0) nmatches[p] = 0; return; }
     __syncthreads();
     hist[t] = 0;
     __syncthreads();
-    for (int i = t; i < n; i += 256) { const int v = sd[i]; if (v >= 0 && ((v >> 8) & 255) == hi) atomicAdd(&hist[v & 255], 1); }
+    for (int i = t; i < n; i += 256) { const int u = sd[i]; if (u >= 0 && ((u >> 8) & 255) == hi) atomicAdd(&hist[u & 255], 1); }
     __syncthreads();
-    if (t == 0) {
-        int acc = 0, lo = 0;
-        for (int b = 0; b < 256; ++b) { if (rank < acc + hist[b]) { lo = b; break; } acc += hist[b]; }
-        s_sel = (hi << 8) | lo;
-    }
+    v = hist[t];
+    incl = orbx_wave_scan(v);
+    if ((t & 63) == 63) wsum[wv] = incl;
+    __syncthreads();
+    for (int i = 0; i < wv; ++i) incl += wsum[i];
+    if (incl - v <= rank && rank < incl) s_sel = (hi << 8) | t;
     __syncthreads();
     const float median = (float)s_sel;
     const float thDist = 1.5f * 1.4f * median;
     int dropped = 0;
     for (int i = t; i < n; i += 256) {
-        const int v = sd[i];
-        if (v >= 0 && (float)v >= thDist) { ur[i] = -1.0f; dp[i] = -1.0f; ++dropped; }
+        const int u = sd[i];
+        if (u >= 0 && (float)u >= thDist) { ur[i] = -1.0f; dp[i] = -1.0f; ++dropped; }
     }
     if (dropped) atomicSub(&s_kept, dropped);
     __syncthreads();
@@ -2305,7 +2311,9 @@ void orbx_launch_quadtree(hipStream_t s, const DGeom &g, int B, const uint2 *den
     static int forced = -1;
     if (forced < 0) { const char *e = getenv("ORBX_QT_THREADS"); forced = e ? atoi(e) : 0; }
     const long long wgs = (long long)B * level_count, cus = g_qt_cus > 0 ? g_qt_cus : 256;
-    int threads = wgs >= 4 * cus ? 256 : wgs >= 2 * cus ? 512 : 1024;
+    int nfeat = 0;   // keys per workgroup scale with the feature quota: 2000 features want 512 threads even at 4 workgroups per CU
+    for (int l = 0; l < g.nlevels; ++l) nfeat += g.lv[l].nfeat;   // (1241x376 / 2000, 128 frames: 77 / 63 / 99 us with 256 / 512 / 1024)
+    int threads = wgs >= 4 * cus && nfeat <= 1600 ? 256 : wgs >= 2 * cus ? 512 : 1024;
     if (forced == 256 || forced == 512 || forced == 1024) threads = forced;
     const dim3 grid = QT_FF ? dim3(B, level_count) : dim3(level_count, B);
     if (threads == 256)
