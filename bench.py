@@ -3,8 +3,9 @@
 
 A step = one pass of the hot path over one batch of synthetic frames already resident in HBM.
   mono configs  : K0..K6 extraction of `--batch` frames (per GPU) + K7 brute-force Hamming match of frame t vs t-1
-  stereo configs: K0..K6 extraction of both eyes of `--batch` stereo pairs (two extractor handles, as src/Frame.cc:158-168
-                  uses two extractor objects) + Frame::ComputeStereoMatches with its median cut, all on the device
+  stereo configs: K0..K6 extraction of both eyes of `--batch` stereo pairs (one extractor batch of 2 x batch images, left
+                  images first; `--stereo-batch split`: two extractor handles, as src/Frame.cc:158-168 uses two extractor
+                  objects) + Frame::ComputeStereoMatches with its median cut, all on the device
   (+ for N > 1 one RCCL gather of the per-frame keypoint records).
 `--config` selects the BASELINE.json configuration (default: the headline one, config 2):
   tum           synthetic 640x480 mono stream, nFeatures 1000      (configs 1/2, Examples/Monocular/TUM1.yaml:30-43)
@@ -38,10 +39,13 @@ N_SIMD = 1024           # 256 CUs x 4 SIMD-32
 PROFILE_TAG = "r02"     # profiles/<tag>_traffic.json, profiles/<tag>_sq.json
 
 CONFIGS = {   # name: (width, height, nfeatures, frames or pairs per GPU per step, stereo, mb, mbf)
-    "tum": (640, 480, 1000, 256, False, 0.0, 0.0),
-    "kitti_stereo": (1241, 376, 2000, 64, True, 0.537, 386.1448),     # bf 386.1448, fx 718.856 (KITTI00-02.yaml)
-    "euroc_stereo": (752, 480, 1200, 128, True, 0.11, 47.90639384423901),   # EuRoC.yaml: Camera.bf
-    "hd1080": (1920, 1080, 4000, 32, False, 0.0, 0.0),
+    # batch sizes: large enough that launch boundaries and the drain of each kernel stop showing (tools/batch_sweep.sh: tum
+    # 256 / 512 / 1024 frames = 249 / 254 / 261 k frames/s; hd1080 32 / 64 / 128 = 38.1 / 41.0 / 43.7 k; KITTI 64 / 128 / 256
+    # pairs = 69.7 / 73.5 / 75.2 k; EuRoC 128 / 256 = 104.0 / 107.9 k); 1024 VGA frames are 1.5 GB of the GPU's 288 GB
+    "tum": (640, 480, 1000, 1024, False, 0.0, 0.0),
+    "kitti_stereo": (1241, 376, 2000, 256, True, 0.537, 386.1448),     # bf 386.1448, fx 718.856 (KITTI00-02.yaml)
+    "euroc_stereo": (752, 480, 1200, 256, True, 0.11, 47.90639384423901),   # EuRoC.yaml: Camera.bf
+    "hd1080": (1920, 1080, 4000, 128, False, 0.0, 0.0),
 }
 
 

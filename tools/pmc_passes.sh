@@ -8,6 +8,6 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
            "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVES" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/p$i -- python3 tools/pmc_probe.py 256 > $out.p$i.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/p$i -- python3 tools/pmc_probe.py ${PMC_BATCH:-1024} > $out.p$i.log 2>&1
   python3 tools/pmc_summarize.py $out/p$i
 done
