@@ -203,6 +203,49 @@ def test_full_batch_of_baseline_config():
     assert total > 60000
 
 
+def test_bench_size_batch_is_frame_independent():
+    """The bench's default step: 1024 frames of 640x480 resident on the device in ONE extractor call, then frame t matched
+    against frame t-1.  The batch repeats 8 distinct frames, so size-independent properties replace 1024 oracle runs: every
+    copy of a frame must come out byte-identical to its first occurrence (frames share no state, include/ORBextractor.h:30-35),
+    the first 8 must equal the oracle, and the match of (t, t-1) must equal the match of the same two base frames."""
+    import torch
+    B, base = 1024, 8
+    w, h, nf = 640, 480, 1000
+    frames = synth.stream(w, h, base, stream_id=100)
+    ex = ORBextractor(nf, max_batch=B)
+    cap = ex.max_keypoints(w, h)
+    dev = torch.device("cuda", 0)
+    d_imgs = torch.from_numpy(frames).to(dev).repeat(B // base, 1, 1).contiguous()
+    kps = torch.zeros((B, cap * 28), dtype=torch.uint8, device=dev); desc = torch.zeros((B, cap * 32), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev); st = torch.zeros(B, dtype=torch.int32, device=dev)
+    mi = torch.full((B, cap), -7, dtype=torch.int32, device=dev); mb = torch.zeros_like(mi); ms = torch.zeros_like(mi)
+    torch.cuda.synchronize()
+    ex.extract_batch_device(d_imgs, B, w, h, w, w * h, kps, desc, cnt, st, cap)
+    L = _capi.lib()
+    # pair p: query = frame p, train = frame p-1 (pair 0: frame B-1, the same base frame as any frame 8k-1)
+    ex.synchronize()          # the rolls below run on torch's stream, which is not ordered with the handle's
+    tr_desc = torch.roll(desc, 1, 0).contiguous(); tr_cnt = torch.roll(cnt, 1, 0).contiguous()
+    torch.cuda.synchronize()
+    _capi.check(L.orbx_match_bruteforce_device(ex.handle, B, _capi.ptr(desc), _capi.ptr(cnt), cap * 32, _capi.ptr(tr_desc), _capi.ptr(tr_cnt),
+                                               cap * 32, _capi.ptr(mi), _capi.ptr(mb), _capi.ptr(ms), cap))
+    ex.synchronize()
+    assert not st.cpu().numpy().any()
+    for t in (kps, desc, mi, mb, ms):
+        v = t.view(B // base, base, -1)
+        assert bool((v == v[0:1]).all()), "a repeated frame came out differently from its first occurrence"
+    assert bool((cnt.view(-1, base) == cnt[:base]).all())
+    orc = oracle.OracleExtractor(nf)
+    outs = [orc.extract(frames[f]) for f in range(base)]
+    n = cnt[:base].cpu().numpy()
+    for f in range(base):
+        k = kps[f].cpu().numpy()[:n[f] * 28].view(_capi.KP_DTYPE); d = desc[f].cpu().numpy()[:n[f] * 32].reshape(-1, 32)
+        assert_frame_equal((k, d), outs[f], f"frame {f}")
+        obi, obd, osd = oracle.match_bruteforce(outs[f][2], outs[(f - 1) % base][2])
+        assert np.array_equal(mi[f, :n[f]].cpu().numpy(), obi) and np.array_equal(mb[f, :n[f]].cpu().numpy(), obd)
+        assert np.array_equal(ms[f, :n[f]].cpu().numpy(), osd)
+        assert (mi[f, n[f]:] == -7).all()
+
+
 # ---------------------------------------------------------------------------------------- matching
 @pytest.fixture(params=["mfma", "valu"])
 def match_kernel(request, monkeypatch):
