@@ -5,6 +5,7 @@
 //   clear counters -> K0 border L0 -> K1 resize x (nlevels-1) -> K2 FAST cells -> K3 quadtree ->
 //   K4 orientation -> K5 blur -> K6 descriptors + assembly.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -117,10 +118,30 @@ extern "C" void orbx_default_params(orbx_params *p) {
 }
 
 // ---------------------------------------------------------------- profiling helpers
+// roctx ranges around every stage's launches: ORBX_ROCTX=1 loads the roctx library at the first use and
+// brackets each ProfScope with roctxRangePushA(slot name) / roctxRangePop, so `rocprofv3 --marker-trace` groups the
+// kernels of a call by stage.  Not linked: without the variable the library has no dependency on the profiler.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *e = getenv("ORBX_ROCTX");
+        if (!e || !atoi(e)) return;
+        void *lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);   // the one rocprofv3 --marker-trace records
+        if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);                 // roctracer's (older tools)
+        if (!lib) return;
+        push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+        pop = (int (*)())dlsym(lib, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+static const Roctx &roctx() { static Roctx r; return r; }
+
 struct ProfScope {
-    orbx_handle *h; int kid; bool on; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    orbx_handle *h; int kid; bool on; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool marked = false;
     ProfScope(orbx_handle *h_, int kid_, hipStream_t st_ = nullptr)
         : h(h_), kid(kid_), on(((h_->prof_mask >> kid_) & 1u) != 0), st(st_ ? st_ : h_->stream) {
+        if (roctx().push) { roctx().push(orbx_kernel_name(kid)); marked = true; }
         if (!on) return;
         a = grab(); b = grab();
         hipEventRecord(a, st);   // events are recorded on the stream the kernel is launched on
@@ -130,6 +151,7 @@ struct ProfScope {
         hipEvent_t e; hipEventCreate(&e); return e;
     }
     ~ProfScope() {
+        if (marked) roctx().pop();
         if (!on) return;
         hipEventRecord(b, st);
         h->pending.push_back({a, b, kid});

@@ -23,6 +23,25 @@ def shard_range(nframes: int, world: int, rank: int):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def shard_ranges_live(nframes: int, world: int, dead=()):
+    """Re-sharding around missing GPUs ("survive a missing GPU by re-sharding -- replicas only, no
+    state"): the blocks of all `world` ranks when the ranks in `dead` take no frames.  The live ranks split the batch as
+    shard_range would for len(live) ranks, in rank order, so the concatenation of the live blocks is the whole batch in
+    frame order whatever the set of dead ranks is; a dead rank gets the empty block at the position where its block would
+    start.  The path keeps no state between frames (include/ORBextractor.h:30-35), so nothing else has to move."""
+    live = [r for r in range(world) if r not in set(dead)]
+    if not live:
+        raise ValueError("no live rank left")
+    out, pos = [], 0
+    for r in range(world):
+        if r in live:
+            b, e = shard_range(nframes, len(live), live.index(r))
+            out.append((b, e)); pos = e
+        else:
+            out.append((pos, pos))
+    return out
+
+
 def record_bytes(cap: int) -> int:
     return 4 + cap * (KP_BYTES + DESC_BYTES)
 

@@ -324,6 +324,17 @@ def test_match_consecutive_frames_and_ratio():
     assert (matches >= 0).sum() > 100                       # the translated scene really matches
 
 
+def test_roctx_ranges_are_optional_and_harmless():
+    """ORBX_ROCTX=1: every stage's launches are bracketed by a roctx range (the library dlopens the roctx runtime; rocprofv3
+    --marker-trace of tools/roctx_probe.py lists them, profiles/r02_roctx_marker_trace.csv).  Without a profiler attached the
+    calls are no-ops and the extraction is the usual one."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "roctx_probe.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "roctx probe done [1008, 1010, 1008, 1005]" in p.stdout
+
+
 def test_profile_counters():
     frames = synth.stream(320, 240, 2, stream_id=9)
     ex = ORBextractor(300, max_batch=2)

@@ -19,6 +19,27 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_resharding_around_dead_ranks_covers_the_batch_in_order():
+    """a missing GPU takes no frames; the live ranks' blocks, in rank order, are the whole batch in frame order (the path is
+    stateless per frame, so re-sharding is only a new plan)"""
+    import itertools
+    for n in (0, 5, 64, 65, 1024):
+        for world in (2, 3, 8):
+            for k in range(0, world):
+                for dead in itertools.islice(itertools.combinations(range(world), k), 12):
+                    blocks = sharding.shard_ranges_live(n, world, dead)
+                    assert len(blocks) == world and all(blocks[r][0] == blocks[r][1] for r in dead)
+                    live = [blocks[r] for r in range(world) if r not in dead]
+                    assert live[0][0] == 0 and live[-1][1] == n and all(live[i][1] == live[i + 1][0] for i in range(len(live) - 1))
+                    sizes = [e - b for b, e in live]
+                    assert max(sizes) - min(sizes) <= 1
+                    if not dead:
+                        assert blocks == [sharding.shard_range(n, world, r) for r in range(world)]
+    import pytest
+    with pytest.raises(ValueError):
+        sharding.shard_ranges_live(8, 2, dead=(0, 1))
+
+
 def _fake_records(rank, frames, cap):
     rng = np.random.default_rng(1000 + rank)
     counts = torch.from_numpy(rng.integers(0, cap + 1, frames).astype(np.int32))
