@@ -327,32 +327,54 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
     }
     src += smin;
     const uint2 *ty = (const uint2 *)taps + L.tapy;
+    // Two destination rows per step.  The horizontal pass of a SOURCE row (h[i] = (a0 * p[s0] + a1 * p[s0+1]) >> 4 for the
+    // lane's four columns) is what cv::resize keeps in its row buffers: destination row Y+1 usually starts on the source row
+    // destination row Y ended on (scale 1.2: 2.4 new source rows per two destination rows instead of 4), so the last row's
+    // h values stay in registers (hp, source row `pid`) and only rows not seen yet are loaded and filtered -- 40 % fewer
+    // loads, 22 % fewer vector instructions per pixel.  All conditions are wave-uniform (scalar branches).
+#define RR_H(dst, v)                                                                                                     \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
+            dst[i] = orbx_udot2(__builtin_amdgcn_perm((v).y, (v).x, sel[i]), wgt[i]) >> 4;                              \
+    }
+#define RR_V(out, h0, h1, w0, w1)                                                                                       \
+    {                                                                                                                   \
+        out = 0;                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
+            out |= (((__umul24(w0, h0[i]) >> 16) + (__umul24(w1, h1[i]) >> 16) + 2u) >> 2) << (8 * i);                  \
+    }
     uint2 ta = ty[y_begin], tb = ty[min(y_begin + 1, L.ph - 1)];
+    int pid = -1;                                   // source row whose horizontal pass hp holds
+    uint32_t hp[4] = {0, 0, 0, 0};
     uint2 ua = orbx_load8(src + (long long)(ta.x & 0xffffu) * S.pitch), wa = orbx_load8(src + (long long)(ta.x >> 16) * S.pitch);
-    uint2 ub = orbx_load8(src + (long long)(tb.x & 0xffffu) * S.pitch), wb = orbx_load8(src + (long long)(tb.x >> 16) * S.pitch);
+    uint2 ub = make_uint2(0, 0), wb = orbx_load8(src + (long long)(tb.x >> 16) * S.pitch);
+    if ((int)(tb.x & 0xffffu) != (int)(ta.x >> 16)) ub = orbx_load8(src + (long long)(tb.x & 0xffffu) * S.pitch);
     for (int Y = y_begin; Y < y_end; Y += 2) {
         const uint2 ca = ta, cb = tb, cua = ua, cwa = wa, cub = ub, cwb = wb;
-        if (Y + 2 < y_end) {   // next step's rows, in flight while this step is evaluated
+        const int a_s0 = (int)(ca.x & 0xffffu), a_s1 = (int)(ca.x >> 16), b_s0 = (int)(cb.x & 0xffffu), b_s1 = (int)(cb.x >> 16);
+        if (Y + 2 < y_end) {   // next step's rows, in flight while this step is evaluated; rows this step leaves in registers are skipped
             ta = ty[Y + 2]; tb = ty[min(Y + 3, L.ph - 1)];
-            ua = orbx_load8(src + (long long)(ta.x & 0xffffu) * S.pitch); wa = orbx_load8(src + (long long)(ta.x >> 16) * S.pitch);
-            ub = orbx_load8(src + (long long)(tb.x & 0xffffu) * S.pitch); wb = orbx_load8(src + (long long)(tb.x >> 16) * S.pitch);
+            const int n_s0 = (int)(ta.x & 0xffffu), n_s1 = (int)(ta.x >> 16), m_s0 = (int)(tb.x & 0xffffu);
+            if (n_s0 != b_s1) ua = orbx_load8(src + (long long)n_s0 * S.pitch);
+            wa = orbx_load8(src + (long long)n_s1 * S.pitch);
+            if (m_s0 != n_s1) ub = orbx_load8(src + (long long)m_s0 * S.pitch);
+            wb = orbx_load8(src + (long long)(tb.x >> 16) * S.pitch);
         }
-        uint32_t va = 0, vb = 0;
-        const uint32_t a0 = ca.y & 0xfffu, a1 = (ca.y >> 16) & 0xfffu, b0 = cb.y & 0xfffu, b1 = (cb.y >> 16) & 0xfffu;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t T0 = orbx_udot2(__builtin_amdgcn_perm(cua.y, cua.x, sel[i]), wgt[i]);
-            const uint32_t T1 = orbx_udot2(__builtin_amdgcn_perm(cwa.y, cwa.x, sel[i]), wgt[i]);
-            const uint32_t T2 = orbx_udot2(__builtin_amdgcn_perm(cub.y, cub.x, sel[i]), wgt[i]);
-            const uint32_t T3 = orbx_udot2(__builtin_amdgcn_perm(cwb.y, cwb.x, sel[i]), wgt[i]);
-            va |= (((__umul24(a0, T0 >> 4) >> 16) + (__umul24(a1, T1 >> 4) >> 16) + 2u) >> 2) << (8 * i);
-            vb |= (((__umul24(b0, T2 >> 4) >> 16) + (__umul24(b1, T3 >> 4) >> 16) + 2u) >> 2) << (8 * i);
-        }
+        uint32_t hq[4], va, vb;
+        if (a_s0 != pid) RR_H(hp, cua)
+        RR_H(hq, cwa)
+        RR_V(va, hp, hq, ca.y & 0xfffu, (ca.y >> 16) & 0xfffu)
+        if (b_s0 != a_s1) RR_H(hq, cub)
+        RR_H(hp, cwb)
+        RR_V(vb, hq, hp, cb.y & 0xfffu, (cb.y >> 16) & 0xfffu)
+        pid = b_s1;
         if (on) {
             *(uint32_t *)(dst + (long long)Y * L.pitch) = va;
             if (Y + 1 < y_end) *(uint32_t *)(dst + (long long)(Y + 1) * L.pitch) = vb;
         }
     }
+#undef RR_H
+#undef RR_V
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2258,7 +2280,7 @@ void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, con
     if (narrow) {
         // destination rows per wave: 16 when the launch still has >= 4096 waves, fewer for small batches (the rows of a
         // wave are a serial chain of load -> evaluate -> store steps)
-        int rpw = 16;
+        int rpw = 16;   // (8 / 16 / 32 / 64 rows per wave at 1024 frames: 750 / 708 / 729 / 742 us for the seven launches)
         while (rpw > 2 && (long long)((L.pw + 255) / 256) * ((L.ph + rpw - 1) / rpw) * B < 4096) rpw >>= 1;
 #if RR_FF
         dim3 grid(B, (L.pw + 255) / 256, (L.ph + RR_WPB * rpw - 1) / (RR_WPB * rpw));
