@@ -332,6 +332,9 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
     // destination row Y ended on (scale 1.2: 2.4 new source rows per two destination rows instead of 4), so the last row's
     // h values stay in registers (hp, source row `pid`) and only rows not seen yet are loaded and filtered -- 40 % fewer
     // loads, 22 % fewer vector instructions per pixel.  All conditions are wave-uniform (scalar branches).
+#ifndef RR_R
+#define RR_R 2
+#endif
 #define RR_H(dst, v)                                                                                                     \
     {                                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
@@ -343,34 +346,42 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
             out |= (((__umul24(w0, h0[i]) >> 16) + (__umul24(w1, h1[i]) >> 16) + 2u) >> 2) << (8 * i);                  \
     }
-    uint2 ta = ty[y_begin], tb = ty[min(y_begin + 1, L.ph - 1)];
-    int pid = -1;                                   // source row whose horizontal pass hp holds
-    uint32_t hp[4] = {0, 0, 0, 0};
-    uint2 ua = orbx_load8(src + (long long)(ta.x & 0xffffu) * S.pitch), wa = orbx_load8(src + (long long)(ta.x >> 16) * S.pitch);
-    uint2 ub = make_uint2(0, 0), wb = orbx_load8(src + (long long)(tb.x >> 16) * S.pitch);
-    if ((int)(tb.x & 0xffffu) != (int)(ta.x >> 16)) ub = orbx_load8(src + (long long)(tb.x & 0xffffu) * S.pitch);
-    for (int Y = y_begin; Y < y_end; Y += 2) {
-        const uint2 ca = ta, cb = tb, cua = ua, cwa = wa, cub = ub, cwb = wb;
-        const int a_s0 = (int)(ca.x & 0xffffu), a_s1 = (int)(ca.x >> 16), b_s0 = (int)(cb.x & 0xffffu), b_s1 = (int)(cb.x >> 16);
-        if (Y + 2 < y_end) {   // next step's rows, in flight while this step is evaluated; rows this step leaves in registers are skipped
-            ta = ty[Y + 2]; tb = ty[min(Y + 3, L.ph - 1)];
-            const int n_s0 = (int)(ta.x & 0xffffu), n_s1 = (int)(ta.x >> 16), m_s0 = (int)(tb.x & 0xffffu);
-            if (n_s0 != b_s1) ua = orbx_load8(src + (long long)n_s0 * S.pitch);
-            wa = orbx_load8(src + (long long)n_s1 * S.pitch);
-            if (m_s0 != n_s1) ub = orbx_load8(src + (long long)m_s0 * S.pitch);
-            wb = orbx_load8(src + (long long)(tb.x >> 16) * S.pitch);
+    // RR_R destination rows per step (even): hb[0] / hb[1] alternate as "row s0" / "row s1" so that no value is ever copied
+    uint2 t[RR_R], u[RR_R], w[RR_R];
+    int pid = -1;                                   // source row whose horizontal pass hb[0] holds at the top of a step
+    uint32_t hb[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int r = 0; r < RR_R; ++r) {
+        t[r] = ty[min(y_begin + r, L.ph - 1)];
+        u[r] = make_uint2(0, 0);
+        if (r == 0 || (int)(t[r].x & 0xffffu) != (int)(t[r - 1].x >> 16)) u[r] = orbx_load8(src + (long long)(t[r].x & 0xffffu) * S.pitch);
+        w[r] = orbx_load8(src + (long long)(t[r].x >> 16) * S.pitch);
+    }
+    for (int Y = y_begin; Y < y_end; Y += RR_R) {
+        uint2 ct[RR_R], cu[RR_R], cw[RR_R];
+#pragma unroll
+        for (int r = 0; r < RR_R; ++r) { ct[r] = t[r]; cu[r] = u[r]; cw[r] = w[r]; }
+        if (Y + RR_R < y_end) {   // next step's rows, in flight while this step is evaluated; rows this step leaves in registers are skipped
+            int last = (int)(ct[RR_R - 1].x >> 16);
+#pragma unroll
+            for (int r = 0; r < RR_R; ++r) {
+                t[r] = ty[min(Y + RR_R + r, L.ph - 1)];
+                const int s0 = (int)(t[r].x & 0xffffu), s1 = (int)(t[r].x >> 16);
+                if (s0 != last) u[r] = orbx_load8(src + (long long)s0 * S.pitch);
+                w[r] = orbx_load8(src + (long long)s1 * S.pitch);
+                last = s1;
+            }
         }
-        uint32_t hq[4], va, vb;
-        if (a_s0 != pid) RR_H(hp, cua)
-        RR_H(hq, cwa)
-        RR_V(va, hp, hq, ca.y & 0xfffu, (ca.y >> 16) & 0xfffu)
-        if (b_s0 != a_s1) RR_H(hq, cub)
-        RR_H(hp, cwb)
-        RR_V(vb, hq, hp, cb.y & 0xfffu, (cb.y >> 16) & 0xfffu)
-        pid = b_s1;
-        if (on) {
-            *(uint32_t *)(dst + (long long)Y * L.pitch) = va;
-            if (Y + 1 < y_end) *(uint32_t *)(dst + (long long)(Y + 1) * L.pitch) = vb;
+#pragma unroll
+        for (int r = 0; r < RR_R; ++r) {
+            uint32_t (&h0)[4] = hb[r & 1], (&h1)[4] = hb[(r & 1) ^ 1];
+            const int s0 = (int)(ct[r].x & 0xffffu);
+            if (s0 != pid) RR_H(h0, cu[r])
+            RR_H(h1, cw[r])
+            uint32_t v;
+            RR_V(v, h0, h1, ct[r].y & 0xfffu, (ct[r].y >> 16) & 0xfffu)
+            pid = (int)(ct[r].x >> 16);
+            if (on && Y + r < y_end) *(uint32_t *)(dst + (long long)(Y + r) * L.pitch) = v;
         }
     }
 #undef RR_H
