@@ -1720,6 +1720,25 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t *__restric
 //           parabola (:1121-1129) uses the same single-rounded float operations as the reference.
 // The final median cut (:1160-1175) is a sort over <= N integers and stays on the host (orbx_api.cpp).
 // ------------------------------------------------------------------------------------------------
+// 16 lanes per LEFT keypoint, four keypoints per wave: every cross-lane step (candidate minimum, the 11 SAD sums) is a DPP
+// rotate inside a row of 16 lanes and serves four keypoints at once, and a wave's chain of dependent loads (keypoint -> row
+// table -> candidates -> descriptors -> best match -> patches) is paid once per four keypoints.  (One wave per keypoint: 330 us
+// per 256 KITTI pairs, 11 x 7 DPP steps and a 5 us load chain per keypoint.)
+__device__ __forceinline__ uint32_t st_row16_min(uint32_t v) {   // all-reduce min inside each row of 16 lanes
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false));   // row_ror:1
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false));   // row_ror:2
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));   // row_ror:4
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));   // row_ror:8
+    return v;
+}
+__device__ __forceinline__ uint32_t st_row16_sum(uint32_t v) {   // all-reduce sum inside each row of 16 lanes
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false);
+    return v;
+}
+#define ST_KPB 16   // left keypoints per 256-thread block
 __device__ __forceinline__ void orbx_stereo_body(const OrbxStereoGeom &sg, const orbx_keypoint *__restrict__ kL,
                                                  const uint8_t *__restrict__ dL, int nL,
                                                  const orbx_keypoint *__restrict__ kR,
@@ -1728,26 +1747,30 @@ __device__ __forceinline__ void orbx_stereo_body(const OrbxStereoGeom &sg, const
                                                  float *__restrict__ uRight, float *__restrict__ depth,
                                                  int *__restrict__ sad, const int *__restrict__ row_begin,
                                                  const uint16_t *__restrict__ row_items) {
-    const int lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (iL >= nL) return;
-    const orbx_keypoint kp = kL[iL];
-    if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; sad[iL] = -1; }
-    const int levelL = kp.octave;
-    const float vL = kp.y, uL = kp.x;
+    // No lane leaves early: the reductions below are DPP operations every lane of the wave takes part in; a keypoint that
+    // drops out (`act`) just stops contributing.
+    const int l16 = threadIdx.x & 15;
+    const int iL = blockIdx.x * ST_KPB + (threadIdx.x >> 4);
+    bool act = iL < nL;
+    float uL = 0.f, vL = 0.f;
+    int levelL = 0;
+    if (act) { const orbx_keypoint kp = kL[iL]; uL = kp.x; vL = kp.y; levelL = kp.octave; }
+    if (act && l16 == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; sad[iL] = -1; }
     const long long row = (long long)vL;
-    if (row < 0 || row >= sg.nrows0) return;                 // F6 clamp (reference: out-of-bounds index)
+    act = act && row >= 0 && row < sg.nrows0;                 // F6 clamp (reference: out-of-bounds index)
     const float maxD = sg.mbf / sg.mb, minD = 0.f;
     const float minU = uL - maxD, maxU = uL - minD;
-    if (maxU < 0) return;
-    const uint4 *qp = (const uint4 *)(dL + (long long)iL * 32);
-    const uint4 qa = qp[0], qb = qp[1];
+    act = act && !(maxU < 0);
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+    if (act) { const uint4 *qp = (const uint4 *)(dL + (long long)iL * 32); qa = qp[0]; qb = qp[1]; }
     uint32_t best = 0xffffffffu;
     if (row_begin) {
         // vRowIndices[vL] of the reference (:926-942), built on the device by k_stereo_rows: only the right keypoints whose
         // row band covers this row are visited (their order does not matter: ties go to the smallest index, as the
         // reference's strict '<' over ascending iR resolves them)
-        for (int j = row_begin[row] + lane; j < row_begin[row + 1]; j += 64) {
+        int j = 0, j1 = 0;
+        if (act) { j = row_begin[row] + l16; j1 = row_begin[row + 1]; }
+        for (; j < j1; j += 16) {
             const int iR = row_items[j];
             const orbx_keypoint kr = kR[iR];
             const bool cand = (int)(kr.octave >= levelL - 1) & (int)(kr.octave <= levelL + 1) & (int)(kr.x >= minU) & (int)(kr.x <= maxU);
@@ -1759,63 +1782,84 @@ __device__ __forceinline__ void orbx_stereo_body(const OrbxStereoGeom &sg, const
                 if (d < 100u) best = min(best, (d << 16) | (uint32_t)iR);
             }
         }
-    } else
-    for (int iR = lane; iR < nR; iR += 64) {
-        const orbx_keypoint kr = kR[iR];
-        const float r = 2.0f * sg.scale[kr.octave];
-        const int maxr = (int)ceilf(kr.y + r), minr = (int)floorf(kr.y - r);
-        const bool cand = (int)(row >= minr) & (int)(row <= maxr) & (int)(kr.octave >= levelL - 1) &
-                          (int)(kr.octave <= levelL + 1) & (int)(kr.x >= minU) & (int)(kr.x <= maxU);
-        if (cand) {
-            const uint4 *tp = (const uint4 *)(dR + (long long)iR * 32);
-            const uint4 ta = tp[0], tb = tp[1];
-            const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
-                               __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
-            if (d < 100u) best = min(best, (d << 16) | (uint32_t)iR);   // bestDist starts at TH_HIGH, strict '<'
+    } else {
+        for (int iR = act ? l16 : nR; iR < nR; iR += 16) {
+            const orbx_keypoint kr = kR[iR];
+            const float r = 2.0f * sg.scale[kr.octave];
+            const int maxr = (int)ceilf(kr.y + r), minr = (int)floorf(kr.y - r);
+            const bool cand = (int)(row >= minr) & (int)(row <= maxr) & (int)(kr.octave >= levelL - 1) &
+                              (int)(kr.octave <= levelL + 1) & (int)(kr.x >= minU) & (int)(kr.x <= maxU);
+            if (cand) {
+                const uint4 *tp = (const uint4 *)(dR + (long long)iR * 32);
+                const uint4 ta = tp[0], tb = tp[1];
+                const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                                   __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+                if (d < 100u) best = min(best, (d << 16) | (uint32_t)iR);   // bestDist starts at TH_HIGH, strict '<'
+            }
         }
     }
-    best = orbx_wave_min(best);
-    if (best == 0xffffffffu || (best >> 16) >= 75u) return;  // thOrbDist = (TH_HIGH + TH_LOW) / 2
-    const int bestIdxR = (int)(best & 0xffffu);
-    const float uR0 = kR[bestIdxR].x;
+    best = st_row16_min(best);
+    act = act && best != 0xffffffffu && (best >> 16) < 75u;   // thOrbDist = (TH_HIGH + TH_LOW) / 2
+    const int bestIdxR = act ? (int)(best & 0xffffu) : 0;
+    float uR0 = 0.f;
+    if (act) uR0 = kR[bestIdxR].x;
     const float scaleFactor = sg.inv_scale[levelL];
-    const float scaleduL = roundf(kp.x * scaleFactor), scaledvL = roundf(kp.y * scaleFactor);
+    const float scaleduL = roundf(uL * scaleFactor), scaledvL = roundf(vL * scaleFactor);
     const float scaleduR0 = roundf(uR0 * scaleFactor);
     const int w = 5, Lh = 5;
     const int W = sg.pw[levelL], H = sg.ph[levelL], pitch = sg.pitch[levelL];
     const int y0 = (int)(scaledvL - w), x0 = (int)(scaleduL - w);
-    if (y0 < 0 || y0 + 2 * w + 1 > H || x0 < 0 || x0 + 2 * w + 1 > W) return;
+    act = act && !(y0 < 0 || y0 + 2 * w + 1 > H || x0 < 0 || x0 + 2 * w + 1 > W);
     const float iniu = scaleduR0 - Lh - w, endu = scaleduR0 + Lh + w + 1;   // fork: minus (src/Frame.cc:1067)
-    if (iniu < 0 || endu >= W) return;
-    const uint8_t *IL = pyrL + sg.off[levelL] + (long long)y0 * pitch + x0;
-    const uint8_t *IR = pyrR + sg.off[levelL] + (long long)y0 * pitch + ((int)scaleduR0 - w);
-    const int cL = IL[w * pitch + w];
-    int acc[11];
+    act = act && !(iniu < 0 || endu >= W);
+    // ---- 11 x 11 patch against 11 shifts: SAD_s = sum |(L - cL) - (R[+s] - cR_s)| = sum |(L + cR_s - cL + 511) - (R[+s] + 511)|
+    // (both sides non-negative 16-bit values).  Two pixels per lane and round in the 16-bit halves of a register: v_perm
+    // picks byte s of both pixels' 12-byte windows of the right image, v_sad_u16 accumulates.  The centre pixel contributes 0 to every shift by construction, so the 7
+    // slots beyond the 121 pixels of the 128 a group walks are filled with it.
+    uint32_t acc[11];
 #pragma unroll
-    for (int s = 0; s < 11; ++s) acc[s] = 0;
-    for (int p = lane; p < 121; p += 64) {
-        const int yy = p / 11, xx = p - yy * 11;
-        const int a = (int)IL[yy * pitch + xx] - cL;
+    for (int s = 0; s < 11; ++s) acc[s] = 0u;
+    if (act) {
+        const uint8_t *IL = pyrL + sg.off[levelL] + (long long)y0 * pitch + x0;
+        const uint8_t *IR = pyrR + sg.off[levelL] + (long long)y0 * pitch + ((int)scaleduR0 - w);
+        const uint32_t cL = IL[w * pitch + w];
+        const orbx_uint3_u cw = *(const orbx_uint3_u *)(IR + w * pitch);   // cR_s = IR[w * pitch + w + (s - Lh)] = byte s
+        uint32_t Cs[11];
 #pragma unroll
         for (int s = 0; s < 11; ++s) {
-            const int inc = s - Lh;
-            const int cR = IR[w * pitch + w + inc];
-            const int b = (int)IR[yy * pitch + xx + inc] - cR;
-            acc[s] += abs(a - b);
+            const uint32_t cwd = s < 4 ? cw.x : s < 8 ? cw.y : cw.z;
+            Cs[s] = (((cwd >> (8 * (s & 3))) & 0xffu) + 511u - cL) * 0x10001u;   // cR_s - cL + 511 in both halves (256 .. 766)
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int q0 = l16 + 16 * k, q1 = q0 + 64;
+            if (q1 >= 121) q1 = 60;                           // the centre pixel: |0 - 0| for every shift
+            const int y_0 = q0 / 11, x_0 = q0 - 11 * y_0, y_1 = q1 / 11, x_1 = q1 - 11 * y_1;
+            const uint32_t L0 = IL[y_0 * pitch + x_0], L1 = IL[y_1 * pitch + x_1];
+            const orbx_uint3_u r0 = *(const orbx_uint3_u *)(IR + y_0 * pitch + x_0 - Lh);   // R bytes x - 5 .. x + 6 of the row
+            const orbx_uint3_u r1 = *(const orbx_uint3_u *)(IR + y_1 * pitch + x_1 - Lh);
+            const uint32_t A0 = L0 | (L1 << 16);               // + Cs[s] = L + cR_s - cL + 511 in both halves (256 .. 1021)
+#pragma unroll
+            for (int s = 0; s < 11; ++s) {
+                const uint32_t lo = s < 4 ? r0.x : s < 8 ? r0.y : r0.z, hi = s < 4 ? r1.x : s < 8 ? r1.y : r1.z;
+                const uint32_t sel = (uint32_t)(s & 3) | (0x0cu << 8) | ((uint32_t)(4 + (s & 3)) << 16) | (0x0cu << 24);
+                const uint32_t B = __builtin_amdgcn_perm(hi, lo, sel) + 0x01ff01ffu;   // R + 511 in both halves
+                acc[s] = __builtin_amdgcn_sad_u16(A0 + Cs[s], B, acc[s]);
+            }
         }
     }
 #pragma unroll
-    for (int s = 0; s < 11; ++s) acc[s] = orbx_wave_sum(acc[s]);
-    if (lane != 0) return;
+    for (int s = 0; s < 11; ++s) acc[s] = st_row16_sum(acc[s]);
+    if (!act || l16 != 0) return;
     int bestDistS = 0x7fffffff, bestinc = 0;
 #pragma unroll
     for (int s = 0; s < 11; ++s)
-        if (acc[s] < bestDistS) { bestDistS = acc[s]; bestinc = s - Lh; }
+        if ((int)acc[s] < bestDistS) { bestDistS = (int)acc[s]; bestinc = s - Lh; }
     if (bestinc == -Lh || bestinc == Lh) return;
     float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
 #pragma unroll
     for (int s = 1; s < 10; ++s)
-        if (s - Lh == bestinc) { dist1 = (float)acc[s - 1]; dist2 = (float)acc[s]; dist3 = (float)acc[s + 1]; }
+        if (s - Lh == bestinc) { dist1 = (float)(int)acc[s - 1]; dist2 = (float)(int)acc[s]; dist3 = (float)(int)acc[s + 1]; }
     const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
     if (deltaR < -1 || deltaR > 1) return;
     float bestuR = sg.scale[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
@@ -2455,7 +2499,7 @@ void orbx_launch_stereo_batch(hipStream_t s, const OrbxStereoGeom &sg, int npair
     const int ipp = orbx_stereo_items_per_pair(sg, cap);
     const bool table = row_begin && row_items && sg.nrows0 <= ST_MAX_ROWS;
     if (table) hipLaunchKernelGGL(k_stereo_rows, dim3(npairs), dim3(1024), 0, s, sg, kR, nR, cap, row_begin, row_items, ipp);
-    hipLaunchKernelGGL(k_stereo_batch, dim3((cap + 3) / 4, npairs), dim3(256), 0, s, sg, kL, dL, nL, kR, dR, nR, cap, pyrL, pyrR,
+    hipLaunchKernelGGL(k_stereo_batch, dim3((cap + ST_KPB - 1) / ST_KPB, npairs), dim3(256), 0, s, sg, kL, dL, nL, kR, dR, nR, cap, pyrL, pyrR,
                        pyr_bytes, uRight, depth, sad, table ? row_begin : nullptr, table ? row_items : nullptr, ipp);
     hipLaunchKernelGGL(k_stereo_cut, dim3(npairs), dim3(256), 0, s, nL, cap, sad, uRight, depth, nmatches);
 }
@@ -2463,7 +2507,7 @@ void orbx_launch_stereo(hipStream_t s, const OrbxStereoGeom &sg, const orbx_keyp
                         const orbx_keypoint *kR, const uint8_t *dR, int nR, const uint8_t *pyrL, const uint8_t *pyrR,
                         float *uRight, float *depth, int *sad) {
     if (nL <= 0) return;
-    hipLaunchKernelGGL(k_stereo, dim3((nL + 3) / 4), dim3(256), 0, s, sg, kL, dL, nL, kR, dR, nR, pyrL, pyrR, uRight,
+    hipLaunchKernelGGL(k_stereo, dim3((nL + ST_KPB - 1) / ST_KPB), dim3(256), 0, s, sg, kL, dL, nL, kR, dR, nR, pyrL, pyrR, uRight,
                        depth, sad);
 }
 
