@@ -1354,11 +1354,11 @@ extern "C" orbx_status orbx_stereo_match_batch_device(orbx_handle *hl, orbx_hand
     }
     const size_t ipp = (size_t)orbx_stereo_items_per_pair(sg, cap);
     st = scratch_reserve(hl, pad256((size_t)npairs * cap * sizeof(int)) + pad256((size_t)npairs * (sg.nrows0 + 1) * sizeof(int)) +
-                                 pad256((size_t)npairs * ipp * sizeof(uint16_t)));
+                                 pad256((size_t)npairs * ipp * sizeof(uint2)));
     if (st != ORBX_OK) return st;
     int *dsad = scratch_take<int>(hl, (size_t)npairs * cap);
     int *drow = scratch_take<int>(hl, (size_t)npairs * (sg.nrows0 + 1));
-    uint16_t *ditems = scratch_take<uint16_t>(hl, (size_t)npairs * ipp);
+    uint2 *ditems = scratch_take<uint2>(hl, (size_t)npairs * ipp);
     { ProfScope ps(hl, ORBX_K_MATCH);
       orbx_launch_stereo_batch(hl->stream, sg, npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, hl->d_pyr,
                                hr->d_pyr + (one_batch ? (size_t)npairs * (size_t)hl->geom.pyr_bytes : 0),

@@ -1746,7 +1746,7 @@ __device__ __forceinline__ void orbx_stereo_body(const OrbxStereoGeom &sg, const
                                                  const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
                                                  float *__restrict__ uRight, float *__restrict__ depth,
                                                  int *__restrict__ sad, const int *__restrict__ row_begin,
-                                                 const uint16_t *__restrict__ row_items) {
+                                                 const uint2 *__restrict__ row_items) {
     // No lane leaves early: the reductions below are DPP operations every lane of the wave takes part in; a keypoint that
     // drops out (`act`) just stops contributing.
     const int l16 = threadIdx.x & 15;
@@ -1771,9 +1771,12 @@ __device__ __forceinline__ void orbx_stereo_body(const OrbxStereoGeom &sg, const
         int j = 0, j1 = 0;
         if (act) { j = row_begin[row] + l16; j1 = row_begin[row + 1]; }
         for (; j < j1; j += 16) {
-            const int iR = row_items[j];
-            const orbx_keypoint kr = kR[iR];
-            const bool cand = (int)(kr.octave >= levelL - 1) & (int)(kr.octave <= levelL + 1) & (int)(kr.x >= minU) & (int)(kr.x <= maxU);
+            // a table entry carries what the gate needs (x, index | octave << 16): one coalesced 8-byte load per lane
+            // instead of a scattered read of the 28-byte keypoint record
+            const uint2 it = row_items[j];
+            const int iR = (int)(it.y & 0xffffu), octR = (int)(it.y >> 16);
+            const float xR = __uint_as_float(it.x);
+            const bool cand = (int)(octR >= levelL - 1) & (int)(octR <= levelL + 1) & (int)(xR >= minU) & (int)(xR <= maxU);
             if (cand) {
                 const uint4 *tp = (const uint4 *)(dR + (long long)iR * 32);
                 const uint4 ta = tp[0], tb = tp[1];
@@ -1889,7 +1892,7 @@ __global__ __launch_bounds__(256) void k_stereo_batch(OrbxStereoGeom sg, const o
                                                       const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
                                                       long long pyr_bytes, float *__restrict__ uRight,
                                                       float *__restrict__ depth, int *__restrict__ sad,
-                                                      const int *__restrict__ row_begin, const uint16_t *__restrict__ row_items,
+                                                      const int *__restrict__ row_begin, const uint2 *__restrict__ row_items,
                                                       int items_per_pair) {
     const long long p = blockIdx.y;
     orbx_stereo_body(sg, kL + p * cap, dL + p * cap * 32, min(nL[p], cap), kR + p * cap, dR + p * cap * 32, min(nR[p], cap),
@@ -1902,7 +1905,7 @@ __global__ __launch_bounds__(256) void k_stereo_batch(OrbxStereoGeom sg, const o
 #define ST_MAX_ROWS 4096
 __global__ __launch_bounds__(1024) void k_stereo_rows(OrbxStereoGeom sg, const orbx_keypoint *__restrict__ kR,
                                                       const int *__restrict__ nR, int cap, int *__restrict__ row_begin,
-                                                      uint16_t *__restrict__ row_items, int items_per_pair) {
+                                                      uint2 *__restrict__ row_items, int items_per_pair) {
     __shared__ int s_cnt[ST_MAX_ROWS + 1];
     __shared__ int s_part[1024];
     const long long p = blockIdx.x;
@@ -1933,13 +1936,13 @@ __global__ __launch_bounds__(1024) void k_stereo_rows(OrbxStereoGeom sg, const o
     for (int y = r0; y < r1; ++y) { const int c = s_cnt[y]; s_cnt[y] = run; rb[y] = run; run += c; }
     if (t == 1023) rb[rows] = s_part[1023];
     __syncthreads();
-    uint16_t *items = row_items + p * items_per_pair;
+    uint2 *items = row_items + p * items_per_pair;
     for (int i = t; i < n; i += 1024) {
         const float r = 2.0f * sg.scale[k[i].octave];
         const int maxr = min((int)ceilf(k[i].y + r), rows - 1), minr = max((int)floorf(k[i].y - r), 0);
         for (int y = minr; y <= maxr; ++y) {
             const int pos = atomicAdd(&s_cnt[y], 1);
-            if (pos < items_per_pair) items[pos] = (uint16_t)i;
+            if (pos < items_per_pair) items[pos] = make_uint2(__float_as_uint(k[i].x), (uint32_t)i | ((uint32_t)k[i].octave << 16));
         }
     }
 }
@@ -2494,7 +2497,7 @@ int orbx_stereo_items_per_pair(const OrbxStereoGeom &sg, int cap) {
 void orbx_launch_stereo_batch(hipStream_t s, const OrbxStereoGeom &sg, int npairs, int cap, const orbx_keypoint *kL,
                               const uint8_t *dL, const int *nL, const orbx_keypoint *kR, const uint8_t *dR, const int *nR,
                               const uint8_t *pyrL, const uint8_t *pyrR, long long pyr_bytes, float *uRight, float *depth,
-                              int *sad, int *nmatches, int *row_begin, uint16_t *row_items) {
+                              int *sad, int *nmatches, int *row_begin, uint2 *row_items) {
     if (npairs <= 0 || cap <= 0) return;
     const int ipp = orbx_stereo_items_per_pair(sg, cap);
     const bool table = row_begin && row_items && sg.nrows0 <= ST_MAX_ROWS;

@@ -44,7 +44,7 @@ void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const u
 void orbx_launch_stereo_batch(hipStream_t s, const OrbxStereoGeom &sg, int npairs, int cap, const orbx_keypoint *kL,
                               const uint8_t *dL, const int *nL, const orbx_keypoint *kR, const uint8_t *dR, const int *nR,
                               const uint8_t *pyrL, const uint8_t *pyrR, long long pyr_bytes, float *uRight, float *depth,
-                              int *sad, int *nmatches, int *row_begin, uint16_t *row_items);
+                              int *sad, int *nmatches, int *row_begin, uint2 *row_items);
 int orbx_stereo_items_per_pair(const OrbxStereoGeom &sg, int cap);
 void orbx_launch_stereo(hipStream_t s, const OrbxStereoGeom &sg, const orbx_keypoint *kL, const uint8_t *dL, int nL,
                         const orbx_keypoint *kR, const uint8_t *dR, int nR, const uint8_t *pyrL, const uint8_t *pyrR,
