@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void k_pyr_l0_remap(DGeom g, const uint8_t *__
 struct __attribute__((packed, aligned(1))) orbx_uint2_u { uint32_t x, y; };   // 8 bytes at any byte address (global memory takes unaligned accesses)
 struct __attribute__((packed, aligned(1))) orbx_uint3_u { uint32_t x, y, z; };
 __device__ __forceinline__ uint2 orbx_load8(const void *p) { const orbx_uint2_u v = *(const orbx_uint2_u *)p; return make_uint2(v.x, v.y); }
+struct __attribute__((aligned(4))) orbx_uint3_a { uint32_t x, y, z; };   // 12 bytes at a dword-aligned address
 typedef unsigned short orbx_v2u16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t orbx_udot2(uint32_t a, uint32_t b) {   // a.lo * b.lo + a.hi * b.hi, exact
     return __builtin_amdgcn_udot2(__builtin_bit_cast(orbx_v2u16, a), __builtin_bit_cast(orbx_v2u16, b), 0u, false);
@@ -325,7 +326,11 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
             wgt[i] = t[i].y;
         }
     }
-    src += smin;
+    // A lane's 8 source bytes start at byte smin of the row: read as the dword-ALIGNED 12-byte window around them and
+    // funnel-shifted in registers (two v_alignbyte).  The per-lane unaligned 8-byte load this replaces (a 4.8-byte lane
+    // stride, 1-byte alignment) was what bounded the kernel: the address unit serves such a wave-load lane by lane.
+    const uint32_t sh = (uint32_t)(smin & 3);
+    src += smin & ~3;
     const uint2 *ty = (const uint2 *)taps + L.tapy;
     // Two destination rows per step.  The horizontal pass of a SOURCE row (h[i] = (a0 * p[s0] + a1 * p[s0+1]) >> 4 for the
     // lane's four columns) is what cv::resize keeps in its row buffers: destination row Y+1 usually starts on the source row
@@ -337,8 +342,9 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
 #endif
 #define RR_H(dst, v)                                                                                                     \
     {                                                                                                                   \
+        const uint32_t lo_ = __builtin_amdgcn_alignbyte((v).y, (v).x, sh), hi_ = __builtin_amdgcn_alignbyte((v).z, (v).y, sh); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
-            dst[i] = orbx_udot2(__builtin_amdgcn_perm((v).y, (v).x, sel[i]), wgt[i]) >> 4;                              \
+            dst[i] = orbx_udot2(__builtin_amdgcn_perm(hi_, lo_, sel[i]), wgt[i]) >> 4;                                  \
     }
 #define RR_V(out, h0, h1, w0, w1)                                                                                       \
     {                                                                                                                   \
@@ -347,18 +353,20 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
             out |= (((__umul24(w0, h0[i]) >> 16) + (__umul24(w1, h1[i]) >> 16) + 2u) >> 2) << (8 * i);                  \
     }
     // RR_R destination rows per step (even): hb[0] / hb[1] alternate as "row s0" / "row s1" so that no value is ever copied
-    uint2 t[RR_R], u[RR_R], w[RR_R];
+    uint2 t[RR_R];
+    orbx_uint3_a u[RR_R], w[RR_R];
     int pid = -1;                                   // source row whose horizontal pass hb[0] holds at the top of a step
     uint32_t hb[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
     for (int r = 0; r < RR_R; ++r) {
         t[r] = ty[min(y_begin + r, L.ph - 1)];
-        u[r] = make_uint2(0, 0);
-        if (r == 0 || (int)(t[r].x & 0xffffu) != (int)(t[r - 1].x >> 16)) u[r] = orbx_load8(src + (long long)(t[r].x & 0xffffu) * S.pitch);
-        w[r] = orbx_load8(src + (long long)(t[r].x >> 16) * S.pitch);
+        u[r].x = u[r].y = u[r].z = 0;
+        if (r == 0 || (int)(t[r].x & 0xffffu) != (int)(t[r - 1].x >> 16)) u[r] = *(const orbx_uint3_a *)(src + (long long)(t[r].x & 0xffffu) * S.pitch);
+        w[r] = *(const orbx_uint3_a *)(src + (long long)(t[r].x >> 16) * S.pitch);
     }
     for (int Y = y_begin; Y < y_end; Y += RR_R) {
-        uint2 ct[RR_R], cu[RR_R], cw[RR_R];
+        uint2 ct[RR_R];
+        orbx_uint3_a cu[RR_R], cw[RR_R];
 #pragma unroll
         for (int r = 0; r < RR_R; ++r) { ct[r] = t[r]; cu[r] = u[r]; cw[r] = w[r]; }
         if (Y + RR_R < y_end) {   // next step's rows, in flight while this step is evaluated; rows this step leaves in registers are skipped
@@ -367,8 +375,8 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
             for (int r = 0; r < RR_R; ++r) {
                 t[r] = ty[min(Y + RR_R + r, L.ph - 1)];
                 const int s0 = (int)(t[r].x & 0xffffu), s1 = (int)(t[r].x >> 16);
-                if (s0 != last) u[r] = orbx_load8(src + (long long)s0 * S.pitch);
-                w[r] = orbx_load8(src + (long long)s1 * S.pitch);
+                if (s0 != last) u[r] = *(const orbx_uint3_a *)(src + (long long)s0 * S.pitch);
+                w[r] = *(const orbx_uint3_a *)(src + (long long)s1 * S.pitch);
                 last = s1;
             }
         }
