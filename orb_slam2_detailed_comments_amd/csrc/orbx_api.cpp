@@ -236,8 +236,12 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
             const size_t budget = (size_t)(160 * 1024) / wg - 512;   // allocation granularity margin
             return budget <= node_part ? 0 : std::min<size_t>({(budget - node_part) / 6, (size_t)4096, (size_t)g.max_cand_cap});
         };
+        // ... and no more than that: key slots beyond `want` only lower the number of workgroups a CU can hold (1024-frame
+        // batches, 640x480 / 1000 features: 2794 slots = 4 workgroups per CU 250 us, 1400 slots 204 us, 600 slots 208 us).
+        // (Launching the small levels on their own with a node table and key slots sized for them -- more workgroups per CU
+        // still -- measured 215-220 us against 200: the second launch boundary costs more than the residency returns.)
         for (int wg = 4; wg >= 2 && keys == 0; --wg)
-            if (fit_at(wg) >= want) keys = fit_at(wg);
+            if (fit_at(wg) >= want) keys = std::max<size_t>(want, 1024);
         // large nfeatures (node tables of tens of KB): two workgroups per CU with the dense levels on the global key map beat
         // one workgroup with every level in LDS -- those levels exceed any LDS budget anyway
         if (keys == 0 && fit_at(2) >= 1024) keys = fit_at(2);
