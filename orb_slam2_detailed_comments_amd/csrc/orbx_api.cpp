@@ -1279,7 +1279,8 @@ extern "C" orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int f
     }
     st = scratch_reserve(hl, pad256((size_t)nl * sizeof(orbx_keypoint)) + pad256((size_t)nl * 32) +
                                  pad256((size_t)std::max(nr, 1) * sizeof(orbx_keypoint)) + pad256((size_t)std::max(nr, 1) * 32) +
-                                 3 * pad256((size_t)nl * sizeof(float)));
+                                 3 * pad256((size_t)nl * sizeof(float)) + pad256((size_t)(sg.nrows0 + 1) * sizeof(int)) +
+                                 pad256((size_t)orbx_stereo_items_per_pair(sg, std::max(nr, 1)) * sizeof(uint2)));
     if (st != ORBX_OK) return st;
     orbx_keypoint *dkl = scratch_take<orbx_keypoint>(hl, nl);
     uint8_t *ddl = scratch_take<uint8_t>(hl, (size_t)nl * 32);
@@ -1287,6 +1288,8 @@ extern "C" orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int f
     uint8_t *ddr = scratch_take<uint8_t>(hl, (size_t)std::max(nr, 1) * 32);
     float *du = scratch_take<float>(hl, nl), *dz = scratch_take<float>(hl, nl);
     int *dsad = scratch_take<int>(hl, nl);
+    int *drow = scratch_take<int>(hl, (size_t)sg.nrows0 + 1);
+    uint2 *ditems = scratch_take<uint2>(hl, (size_t)orbx_stereo_items_per_pair(sg, std::max(nr, 1)));
     HIPCHK(hipMemcpyAsync(dkl, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, hl->stream));
     HIPCHK(hipMemcpyAsync(ddl, dl, (size_t)nl * 32, hipMemcpyHostToDevice, hl->stream));
     if (nr > 0) {
@@ -1295,7 +1298,7 @@ extern "C" orbx_status orbx_stereo_match(orbx_handle *hl, orbx_handle *hr, int f
     }
     { ProfScope ps(hl, ORBX_K_MATCH);
       orbx_launch_stereo(hl->stream, sg, dkl, ddl, nl, dkr, ddr, nr, hl->d_pyr + (size_t)frame_left * hl->geom.pyr_bytes,
-                         hr->d_pyr + (size_t)frame_right * hr->geom.pyr_bytes, du, dz, dsad); }
+                         hr->d_pyr + (size_t)frame_right * hr->geom.pyr_bytes, du, dz, dsad, drow, ditems); }
     std::vector<int> sad(nl);
     HIPCHK(hipMemcpyAsync(u_right, du, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, hl->stream));
     HIPCHK(hipMemcpyAsync(depth, dz, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, hl->stream));

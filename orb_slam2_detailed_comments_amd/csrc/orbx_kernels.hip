@@ -1889,8 +1889,9 @@ __global__ __launch_bounds__(256) void k_stereo(OrbxStereoGeom sg, const orbx_ke
                                                 const uint8_t *__restrict__ dR, int nR,
                                                 const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
                                                 float *__restrict__ uRight, float *__restrict__ depth,
-                                                int *__restrict__ sad) {
-    orbx_stereo_body(sg, kL, dL, nL, kR, dR, nR, pyrL, pyrR, uRight, depth, sad, nullptr, nullptr);
+                                                int *__restrict__ sad, const int *__restrict__ row_begin,
+                                                const uint2 *__restrict__ row_items) {
+    orbx_stereo_body(sg, kL, dL, nL, kR, dR, nR, pyrL, pyrR, uRight, depth, sad, row_begin, row_items);
 }
 // batched: blockIdx.y = stereo pair; keypoints / descriptors / results of pair p at p * cap, pyramids at p * pyr_bytes
 __global__ __launch_bounds__(256) void k_stereo_batch(OrbxStereoGeom sg, const orbx_keypoint *__restrict__ kL,
@@ -1913,11 +1914,11 @@ __global__ __launch_bounds__(256) void k_stereo_batch(OrbxStereoGeom sg, const o
 #define ST_MAX_ROWS 4096
 __global__ __launch_bounds__(1024) void k_stereo_rows(OrbxStereoGeom sg, const orbx_keypoint *__restrict__ kR,
                                                       const int *__restrict__ nR, int cap, int *__restrict__ row_begin,
-                                                      uint2 *__restrict__ row_items, int items_per_pair) {
+                                                      uint2 *__restrict__ row_items, int items_per_pair, int n_direct) {
     __shared__ int s_cnt[ST_MAX_ROWS + 1];
     __shared__ int s_part[1024];
     const long long p = blockIdx.x;
-    const int t = threadIdx.x, n = min(nR[p], cap), rows = sg.nrows0;
+    const int t = threadIdx.x, n = nR ? min(nR[p], cap) : n_direct, rows = sg.nrows0;   // (single pair: the count comes by value)
     const orbx_keypoint *k = kR + p * cap;
     for (int i = t; i <= rows; i += 1024) s_cnt[i] = 0;
     __syncthreads();
@@ -2509,16 +2510,22 @@ void orbx_launch_stereo_batch(hipStream_t s, const OrbxStereoGeom &sg, int npair
     if (npairs <= 0 || cap <= 0) return;
     const int ipp = orbx_stereo_items_per_pair(sg, cap);
     const bool table = row_begin && row_items && sg.nrows0 <= ST_MAX_ROWS;
-    if (table) hipLaunchKernelGGL(k_stereo_rows, dim3(npairs), dim3(1024), 0, s, sg, kR, nR, cap, row_begin, row_items, ipp);
+    if (table) hipLaunchKernelGGL(k_stereo_rows, dim3(npairs), dim3(1024), 0, s, sg, kR, nR, cap, row_begin, row_items, ipp, 0);
     hipLaunchKernelGGL(k_stereo_batch, dim3((cap + ST_KPB - 1) / ST_KPB, npairs), dim3(256), 0, s, sg, kL, dL, nL, kR, dR, nR, cap, pyrL, pyrR,
                        pyr_bytes, uRight, depth, sad, table ? row_begin : nullptr, table ? row_items : nullptr, ipp);
     hipLaunchKernelGGL(k_stereo_cut, dim3(npairs), dim3(256), 0, s, nL, cap, sad, uRight, depth, nmatches);
 }
 void orbx_launch_stereo(hipStream_t s, const OrbxStereoGeom &sg, const orbx_keypoint *kL, const uint8_t *dL, int nL,
                         const orbx_keypoint *kR, const uint8_t *dR, int nR, const uint8_t *pyrL, const uint8_t *pyrR,
-                        float *uRight, float *depth, int *sad) {
+                        float *uRight, float *depth, int *sad, int *row_begin, uint2 *row_items) {
     if (nL <= 0) return;
+    // the row table of the batched form (vRowIndices) for the one pair too: without it a left keypoint's 16 lanes walk every
+    // right keypoint
+    const bool table = row_begin && row_items && sg.nrows0 <= ST_MAX_ROWS && nR > 0;
+    if (table)
+        hipLaunchKernelGGL(k_stereo_rows, dim3(1), dim3(1024), 0, s, sg, kR, (const int *)nullptr, nR, row_begin, row_items,
+                           orbx_stereo_items_per_pair(sg, nR), nR);
     hipLaunchKernelGGL(k_stereo, dim3((nL + ST_KPB - 1) / ST_KPB), dim3(256), 0, s, sg, kL, dL, nL, kR, dR, nR, pyrL, pyrR, uRight,
-                       depth, sad);
+                       depth, sad, table ? row_begin : nullptr, table ? row_items : nullptr);
 }
 

@@ -48,4 +48,4 @@ void orbx_launch_stereo_batch(hipStream_t s, const OrbxStereoGeom &sg, int npair
 int orbx_stereo_items_per_pair(const OrbxStereoGeom &sg, int cap);
 void orbx_launch_stereo(hipStream_t s, const OrbxStereoGeom &sg, const orbx_keypoint *kL, const uint8_t *dL, int nL,
                         const orbx_keypoint *kR, const uint8_t *dR, int nR, const uint8_t *pyrL, const uint8_t *pyrR,
-                        float *uRight, float *depth, int *sad);
+                        float *uRight, float *depth, int *sad, int *row_begin, uint2 *row_items);

@@ -17,11 +17,14 @@ from test_bow_policies import make_featvec
 
 
 def bench(fn, reps):
+    """median of the per-call wall times (a mean over 30 calls moves by hundreds of us with one scheduling hiccup of the host)"""
     fn()
-    t = time.perf_counter()
+    ts = []
     for _ in range(reps):
+        t = time.perf_counter()
         fn()
-    return (time.perf_counter() - t) / reps * 1e6
+        ts.append(time.perf_counter() - t)
+    return float(np.median(ts)) * 1e6
 
 
 def main():
