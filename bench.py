@@ -244,24 +244,22 @@ def main():
         k = i % NS
         e, st, b = exs[k], streams[k], bufs[k]
         with torch.cuda.stream(st):
-            if merged:
+            if merged:       # stereo, both eyes through one extractor batch: left images in [0, B), right images in [B, 2B)
                 e.extract_batch_device(d_both, 2 * B, W, H, W, W * H, b["kpsM"], b["descM"], b["countsM"], b["statusM"], cap)
                 _capi.check(L.orbx_stereo_match_batch_device(
                     e.handle, e.handle, B, _capi.ptr(b["kpsM"][:B]), _capi.ptr(b["descM"][:B]), _capi.ptr(b["countsM"][:B]),
                     _capi.ptr(b["kpsM"][B:]), _capi.ptr(b["descM"][B:]), _capi.ptr(b["countsM"][B:]), cap, mb, mbf,
                     _capi.ptr(b["uright"]), _capi.ptr(b["depth"]), _capi.ptr(b["nmatch"])))
-            else:
+            elif stereo:     # one extractor handle and batch per eye
                 e.extract_batch_device(d_imgs, B, W, H, W, W * H, b["kps"][1:], b["desc"][1:], b["counts"][1:], b["status"], cap)
-            if merged:
-                pass
-            elif stereo:
                 with torch.cuda.stream(stream_r):
                     exR.extract_batch_device(d_right, B, W, H, W, W * H, b["kpsR"], b["descR"], b["countsR"], b["statusR"], cap)
                 _capi.check(L.orbx_stereo_match_batch_device(
                     e.handle, exR.handle, B, _capi.ptr(b["kps"][1:]), _capi.ptr(b["desc"][1:]), _capi.ptr(b["counts"][1:]),
                     _capi.ptr(b["kpsR"]), _capi.ptr(b["descR"]), _capi.ptr(b["countsR"]), cap, mb, mbf,
                     _capi.ptr(b["uright"]), _capi.ptr(b["depth"]), _capi.ptr(b["nmatch"])))
-            else:
+            else:            # mono: extract, then frame t against frame t-1
+                e.extract_batch_device(d_imgs, B, W, H, W, W * H, b["kps"][1:], b["desc"][1:], b["counts"][1:], b["status"], cap)
                 if i > 0 and NS > 1:
                     st.wait_event(carry_ready)      # slot 0 was filled at the end of step i-1 on another pipeline's stream
                 _capi.check(L.orbx_match_bruteforce_device(
