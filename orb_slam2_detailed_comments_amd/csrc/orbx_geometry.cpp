@@ -185,7 +185,8 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
             }
         }
     }
-    // FAST wave groups: pair a cell with its right-hand neighbour when both interiors fit the 64 lanes of a wave
+    // FAST wave groups: pair a cell with its right-hand neighbour when both interiors fit the 64 lanes of a wave plus the
+    // ORBX_FAST_XCOLS columns k_fast_rows tests outside its row walk (two 33-column cells: 66)
     for (size_t i = 0; i < g.cells.size();) {
         const OrbxCell &a = g.cells[i];
         OrbxFastGroup grp;
@@ -194,7 +195,7 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
             const OrbxCell &b = g.cells[i + 1];
             const bool adjacent = b.level == a.level && b.y0 == a.y0 && b.ch == a.ch && b.x0 == a.x0 + a.cw - 6 &&
                                   b.idx_in_level == a.idx_in_level + 1;
-            if (adjacent && (a.cw - 6) + (b.cw - 6) <= 64) grp.ncell = 2;
+            if (adjacent && (a.cw - 6) + (b.cw - 6) <= 64 + ORBX_FAST_XCOLS) grp.ncell = 2;
         }
         g.fast_groups.push_back(grp);
         i += (size_t)grp.ncell;

@@ -21,7 +21,9 @@ struct OrbxCell {
 };
 
 // One wave of k_fast_rows: `ncell` (1 or 2) horizontally adjacent cells of one cell row whose interiors together span
-// at most 64 columns (one lane per interior column).
+// at most 64 + ORBX_FAST_XCOLS columns (one lane per interior column in the row walk; the columns beyond the wave are tested
+// apart, lanes as rows).  The LDS tile pitch of the kernel bounds it: 64 + XCOLS + 6 ring + 3 alignment bytes <= 76.
+#define ORBX_FAST_XCOLS 2
 struct OrbxFastGroup {
     int32_t cell0;
     int32_t ncell;

@@ -457,6 +457,8 @@ __device__ __forceinline__ fr_u16 fr_min(fr_u16 a, fr_u16 b) { return a < b ? a 
 __device__ __forceinline__ fr_i16 fr_smax(fr_i16 a, fr_i16 b) { return a > b ? a : b; }
 __device__ __forceinline__ fr_i16 fr_smin(fr_i16 a, fr_i16 b) { return a < b ? a : b; }
 
+static_assert(64 + ORBX_FAST_XCOLS + 6 + 3 <= FR_TP, "a cell pair's tile row must fit the LDS tile pitch");
+__device__ __forceinline__ bool colx_on_mask(unsigned act) { return (act & 2u) != 0; }   // columns >= 64 belong to the second cell
 struct FrCtx {
     const uint8_t *tile;   // LDS tile, byte (0,0) = sub-mat origin of the group's first cell
     uint8_t *score;        // LDS score map, same coordinates
@@ -703,7 +705,12 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         // lanes that are switched off (outside the group, or a cell that already has keypoints) carry a threshold no
         // 8-bit difference reaches: the pre-test needs no separate lane mask
         const fr_i16 thv = lane_on ? (fr_i16)th : (fr_i16)0x4000;
-        while (y < yend) {
+        // A pair of cells may be up to ORBX_FAST_XCOLS columns wider than the wave (two 33-column cells: level 2 and 5 of 640x480 would
+        // otherwise run one cell per wave, half the lanes idle; ORBX_FAST_XCOLS).  The row walk covers columns 0..63; the columns beyond are
+        // tested afterwards with the lanes as ROWS, one column per step, into the same work list.
+        int xc = 64;
+        const fr_i16 thx = (colx_on_mask(act) && 3 + lane < yend) ? (fr_i16)th : (fr_i16)0x4000;
+        while (y < yend || xc < niw) {
             // ---- compass pre-test, one row per step: a 9-arc of the 16-ring contains one pixel of every opposite
             // pair, so max(min(max(r0,r8),max(r4,r12)) - v, v - max(min(r0,r8),min(r4,r12))) > th is necessary.
             // The column window (rows y-3 .. y+3) rotates through seven registers: one new LDS byte per row.
@@ -754,6 +761,18 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
                 ++y;
             }
 #undef FR_STEP
+            // the columns beyond the wave (rows done): lane = row 3 + lane, one column per step while the list takes 64 more
+            while (y >= yend && xc < niw && nb + 128u <= list0 + 2u * (uint32_t)lcap) {
+                const uint8_t *px = cx.tile + (3 + lane) * FR_TP + 3 + xc;
+                const fr_u16 C = px[0], r0 = px[-3 * FR_TP], r8 = px[3 * FR_TP], r4 = px[3], r12 = px[-3];
+                const fr_u16 A = fr_min(fr_max(r0, r8), fr_max(r4, r12));
+                const fr_u16 Bm = fr_max(fr_min(r0, r8), fr_min(r4, r12));
+                const bool cnd = fr_smax((fr_i16)(A - C), (fr_i16)(C - Bm)) > thx;
+                const unsigned long long m = orbx_ballot(cnd);
+                if (cnd) *(fr_lds_u16 *)(uintptr_t)(nb + 2u * (uint32_t)orbx_wave_rank(m)) = (uint16_t)(((3 + lane) << 8) | xc);
+                nb += 2u * (uint32_t)__popcll(m);
+                ++xc;
+            }
             const int n = (int)((nb - list0) >> 1);
             orbx_wave_sync();
             if (dbg_stop == 2) { if (n == 12345) cand_cursor[0] = n; continue; }
@@ -773,12 +792,19 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         if (!overflow) {
             fr_nms(cx, gc, s_corn, nctot, a0, a1);
         } else {
-            for (int yy = 3; yy < yend;) {
+            int xs = 64;
+            for (int yy = 3; yy < yend || xs < niw;) {
                 int n = 0;
                 for (; yy < yend && n + 64 <= lcap; ++yy) {
                     const bool cnd = lane_on && s_score[yy * FR_TP + 3 + lane] != 0;
                     const unsigned long long m = orbx_ballot(cnd);
                     if (cnd) s_list[n + orbx_wave_rank(m)] = (uint16_t)((yy << 8) | lane);
+                    n += __popcll(m);
+                }
+                for (; yy >= yend && xs < niw && n + 64 <= lcap; ++xs) {   // columns beyond the wave: lane = row
+                    const bool cnd = colx_on_mask(act) && 3 + lane < yend && s_score[(3 + lane) * FR_TP + 3 + xs] != 0;
+                    const unsigned long long m = orbx_ballot(cnd);
+                    if (cnd) s_list[n + orbx_wave_rank(m)] = (uint16_t)(((3 + lane) << 8) | xs);
                     n += __popcll(m);
                 }
                 orbx_wave_sync();

@@ -1,7 +1,7 @@
 // Sanitizer driver for the HIP-free host translation unit csrc/orbx_geometry.cpp (tests/test_sanitizers.py builds it with
 // g++ -fsanitize=address,undefined): tables + geometry for BASELINE.json's sizes and a sweep of odd sizes / scale factors,
 // with the invariants the kernels rely on checked on the way (cells inside their level, taps inside the source level,
-// slot ranges disjoint and inside the level's candidate region, FAST groups <= 64 interior columns).
+// slot ranges disjoint and inside the level's candidate region, FAST groups <= 64 + ORBX_FAST_XCOLS interior columns).
 #include <cstdio>
 #include <cstdlib>
 #include "../orb_slam2_detailed_comments_amd/csrc/orbx_internal.h"
@@ -43,7 +43,7 @@ static void one(int w, int h, int nf, float sf, int nl) {
     for (const OrbxFastGroup &G : g.fast_groups) {
         CHECK(G.ncell == 1 || G.ncell == 2);
         const OrbxCell &a = g.cells[(size_t)G.cell0], &b = g.cells[(size_t)G.cell0 + G.ncell - 1];
-        CHECK(a.level == b.level && a.y0 == b.y0 && b.x0 + b.cw - a.x0 - 6 <= 64);
+        CHECK(a.level == b.level && a.y0 == b.y0 && b.x0 + b.cw - a.x0 - 6 <= 64 + ORBX_FAST_XCOLS);
     }
 }
 
