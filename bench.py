@@ -94,7 +94,8 @@ def committed_counters(kind, cfg_name, B, W, H, NF):
     Returns None unless the file was taken on THIS workload with THIS device code (kernel source hash): a stale file reads
     as 'not measured', never as a number."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{kind}.json")))
+        name = f"{PROFILE_TAG}_{kind}.json" if cfg_name == "tum" else f"{PROFILE_TAG}_{kind}_{cfg_name}.json"
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
         if t.get("kernels_sha256_16") != kernels_hash():
             return None
         if (t["batch"], t["width"], t["height"], t["nfeatures"]) != (B, W, H, NF) or t.get("config", "tum") != cfg_name:

@@ -2,7 +2,7 @@
 """profiles/r0N_sq.json from separate rocprofv3 --pmc passes (tools/pmc_passes.sh) over tools/pmc_probe.py: SQ wave-instruction
 counts per launch of every profiling slot, keyed like bench.py's kernel slots, with the hash of the device code they belong to.
 
-  tools/make_sq_json.py PMC_DIR_PREFIX OUT.json [batch width height nfeatures]      (PMC_DIR_PREFIX/p1 .. p4)
+  tools/make_sq_json.py PMC_DIR_PREFIX OUT.json [batch width height nfeatures [config]]      (PMC_DIR_PREFIX/p1 .. p4)
 bench.py's roofline.issue_frac = (SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_INSTS_LDS) of the dominant kernel over the issue slots of its
 LIVE launch duration (1024 SIMDs, one wave64 instruction per 2 cycles, 2.4 GHz)."""
 import csv, collections, glob, json, os, sys
@@ -10,12 +10,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from orb_slam2_detailed_comments_amd import build
 
 SLOTS = {"k_pyr_l0": ["k_pyr_l0"], "k_pyr_resize": ["k_pyr_resize_rows", "k_pyr_resize"], "k_fast_rows": ["k_fast_rows"],
-         "k_quadtree": ["k_quadtree"], "k_describe": ["k_describe"], "k_match": ["k_match", "k_match_merge"]}
+         "k_quadtree": ["k_quadtree"], "k_describe": ["k_describe"], "k_match": ["k_match", "k_match_merge", "k_stereo_rows", "k_stereo_batch", "k_stereo_cut"]}
 
 
 def main():
     prefix, out = sys.argv[1:3]
     B, W, H, NF = (int(a) for a in sys.argv[3:7]) if len(sys.argv) >= 7 else (256, 640, 480, 1000)
+    config = sys.argv[7] if len(sys.argv) >= 8 else "tum"     # bench.py --config name the counters were taken on
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for fn in glob.glob(prefix + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
@@ -35,7 +36,7 @@ def main():
             continue
         kernels[slot] = {c: int(v / launches) for c, v in sorted(cs.items())}   # per launch of the slot
         kernels[slot]["launches_per_step"] = launches / steps
-    json.dump({"config": "tum", "kernels_sha256_16": build.kernels_hash(), "batch": B, "width": W, "height": H, "nfeatures": NF,
+    json.dump({"config": config, "kernels_sha256_16": build.kernels_hash(), "batch": B, "width": W, "height": H, "nfeatures": NF,
                "steps_profiled": steps, "unit": "wave-instructions (or the counter's own unit) per launch", "kernels": kernels},
               open(out, "w"), indent=1)
     print(open(out).read())

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/r0N_traffic.json from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/pmc_probe.py.
 
-  tools/make_traffic_json.py FETCH_DIR WRITE_DIR OUT.json [batch width height nfeatures]
+  tools/make_traffic_json.py FETCH_DIR WRITE_DIR OUT.json [batch width height nfeatures [config]]
 
 HBM bytes per launch = FETCH_SIZE[KB] * 1024 * 2 (gfx950 calibration, tools/fetch_calib.hip) + WRITE_SIZE[KB] * 1024.
 Entries are keyed by the profiling slot bench.py uses (k_pyr_l0, k_pyr_resize, k_fast_rows, ...); the device kernels
@@ -16,7 +16,7 @@ SLOTS = {
     "k_fast_rows": ["k_fast_rows"],
     "k_quadtree": ["k_quadtree"],
     "k_describe": ["k_describe"],
-    "k_match": ["k_match", "k_match_merge"],
+    "k_match": ["k_match", "k_match_merge", "k_stereo_rows", "k_stereo_batch", "k_stereo_cut"],   # (stereo configs: the stereo match)
 }
 
 
@@ -33,6 +33,7 @@ def collect(path, counter):
 def main():
     fdir, wdir, out = sys.argv[1:4]
     B, W, H, NF = (int(a) for a in sys.argv[4:8]) if len(sys.argv) >= 8 else (256, 640, 480, 1000)
+    config = sys.argv[8] if len(sys.argv) >= 9 else "tum"     # bench.py --config name the counters were taken on
     fe, wr = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
     steps = len(fe.get("k_describe", [])) or 1
     kernels = {}
@@ -49,7 +50,7 @@ def main():
             "hbm_bytes_per_launch": int((f_kb * 2.0 + w_kb) * 1024 / launches),
         }
     total = sum(k["hbm_bytes_per_launch"] * k["launches_per_step"] for k in kernels.values())
-    json.dump({"config": "tum", "kernels_sha256_16": build.kernels_hash(), "batch": B, "width": W, "height": H, "nfeatures": NF, "steps_profiled": steps,
+    json.dump({"config": config, "kernels_sha256_16": build.kernels_hash(), "batch": B, "width": W, "height": H, "nfeatures": NF, "steps_profiled": steps,
                "calibration": {"FETCH_SIZE_factor": 2.0, "WRITE_SIZE_factor": 1.0,
                                "how": "tools/fetch_calib.hip streams 512 MiB once with 4 B/lane, 16 B/lane and 64-byte row "
                                       "segments: FETCH_SIZE reports exactly 1/2 for all three, WRITE_SIZE is exact"},

@@ -21,4 +21,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $o/r02_${tag}_prof_kitti
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $o/r02_${tag}_pmc_fetch -- python3 tools/pmc_probe.py 1024 > $o/r02_${tag}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o/r02_${tag}_pmc_write -- python3 tools/pmc_probe.py 1024 > $o/r02_${tag}_pmc_write.log 2>&1
 bash tools/pmc_passes.sh $o/r02_${tag}_pmc_sq > $o/r02_${tag}_pmc_sq.log 2>&1
+bash tools/r02_profiles_configs.sh $tag
 echo profiles done
