@@ -383,7 +383,27 @@ def test_bench_line_contract():
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in j
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "u8" and j["value"] > 1000
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "issue_frac")) <= set(j["roofline"])
+    assert j["roofline"]["traffic"] is None            # counters are committed for the default batch only: never a stale number
+    assert j["roofline_mfma"]["kernel"] == "k_match" and j["roofline_mfma"]["bound"] == "mfma"
+
+
+@pytest.mark.parametrize("mode", ["merged", "split"])
+def test_bench_line_contract_stereo(mode):
+    """the stereo configurations print the same contract line, with both eyes through one extractor batch (default) or one batch
+    per eye"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "euroc_stereo", "--stereo-batch", mode, "--steps", "2",
+                        "--warmup", "1", "--batch", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    j = json.loads(line[0])
+    assert "stereo" in j["metric"] and j["config"]["name"] == "euroc_stereo" and j["config"]["frames_per_gpu_per_step"] == 4
+    assert j["config"]["images_per_s"] == pytest.approx(2 * j["value"], rel=1e-3)
+    assert ("one extractor batch of 8 images" in j["config"]["workload"]) == (mode == "merged")
+    assert j["roofline"]["kernel"] in ("k_fast_rows", "k_describe", "k_pyr_resize", "k_match", "k_quadtree", "k_pyr_l0")
 
 
 @pytest.mark.parametrize("fmt,nch,rgb", [(_capi.FMT_RGB8, 3, True), (_capi.FMT_BGR8, 3, False), (_capi.FMT_RGBA8, 4, True),
