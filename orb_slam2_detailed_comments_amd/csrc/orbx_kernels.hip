@@ -1255,6 +1255,9 @@ __constant__ uint32_t c_orient_w[64][12];
 // fixed-point row pass over it (4 pixels per item, as k_blur does) and evaluates the column pass only at the 512 tap
 // positions.  The blurred image is never written: 2P bytes of HBM traffic per frame disappear.  Arithmetic is the
 // same as k_blur's (8-bit kernel, float column path for x < (w & ~3), integer tail), so descriptors are unchanged.
+#ifndef DS_ORDER
+#define DS_ORDER 1
+#endif
 #define DS_R 21                 // patch radius: 18 (taps) + 3 (filter support)
 #define DS_W (2 * DS_R + 1)     // 43
 #define DS_PP 44                // LDS patch pitch in bytes (11 dwords; rows start dword-aligned in LDS)
@@ -1286,7 +1289,7 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
                                                   const int *__restrict__ lvl_count,
                                                   float *__restrict__ lvl_angle, orbx_keypoint *__restrict__ kps,
                                                   uint8_t *__restrict__ desc, int *__restrict__ counts,
-                                                  int *__restrict__ status, int cap, int dbg_stop) {
+                                                  int *__restrict__ status, int cap, int dbg_stop, int nframes) {
     // dbg_stop (ORBX_DESC_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS): 1 = after staging, 2 = after orientation,
     // 3 = after the row pass.  The shipped library pins it to 0.
 #ifndef ORBX_TIMING_KNOBS
@@ -1298,8 +1301,19 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
     // The wave index is wave-uniform (which the compiler cannot see): with it scalar, the level search and the position
     // load run on the scalar unit.
     const int lane = threadIdx.x & 63, wv_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Workgroup order (x fastest): frame mod 8, then keypoint, then frame / 8.  Workgroups are dealt round-robin over the 8
+    // XCDs, so XCD x works through the keypoints of frame 8k + x one after the other with that frame's 1.2 MB pyramid in its
+    // own 4 MB L2, and the chip holds 8 frames at a time.  (With the frame as the fastest index -- the order of the first
+    // version -- every frame of the batch has a few keypoints in flight at once: at 1024 frames per launch no cache holds that,
+    // and every patch came from HBM, 3.1 MB per frame.)
+#if DS_ORDER == 1
+    const int f = blockIdx.y * 8 + (blockIdx.x & 7);
+    const int oi = (blockIdx.x >> 3) * DS_WPB + wv_id;
+    if (f >= nframes) return;
+#else
     const int f = blockIdx.x;   // frame fastest: one frame's patches stay in one XCD's L2
     const int oi = blockIdx.y * DS_WPB + wv_id;
+#endif
     const int *lc = lvl_count + f * g.nlevels;
     int total = 0, level = 0, slot = oi;
 #pragma unroll
@@ -1309,7 +1323,7 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
             total += lc[l];
         }
     }
-    if (blockIdx.y == 0 && wv_id == 0 && lane == 0) {
+    if (oi == 0 && lane == 0) {
         counts[f] = min(total, cap);
         if (total > cap) atomicMax(&status[f], (int)ORBX_CAPACITY);
     }
@@ -2467,11 +2481,15 @@ void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *p
 #else
     const int dbg_stop = 0;
 #endif
+#if DS_ORDER == 1
+    const dim3 grid(8 * ((g.kp_total + DS_WPB - 1) / DS_WPB), (B + 7) / 8);
+#else
     const dim3 grid(B, (g.kp_total + DS_WPB - 1) / DS_WPB);
+#endif
     if (g.fp_mode == ORBX_FP_GCC_FMA)
-        hipLaunchKernelGGL(k_describe<ORBX_FP_GCC_FMA>, grid, dim3(64 * DS_WPB), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
+        hipLaunchKernelGGL(k_describe<ORBX_FP_GCC_FMA>, grid, dim3(64 * DS_WPB), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop, B);
     else
-        hipLaunchKernelGGL(k_describe<ORBX_FP_STRICT>, grid, dim3(64 * DS_WPB), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop);
+        hipLaunchKernelGGL(k_describe<ORBX_FP_STRICT>, grid, dim3(64 * DS_WPB), 0, s, g, pyr, lvl_kp, lvl_count, lvl_angle, kps, desc, counts, status, cap, dbg_stop, B);
 }
 void orbx_launch_grid_build(hipStream_t s, const DGrid &gp, int nframes, const orbx_keypoint *kps, const int *counts, int fixed_n,
                             int cap, int *cell_begin, uint16_t *items) {
