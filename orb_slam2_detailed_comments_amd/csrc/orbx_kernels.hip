@@ -288,6 +288,9 @@ __global__ __launch_bounds__(256) void k_pyr_resize(DGeom g, int level, const Or
 // the source rows of step k+1 are requested before step k is evaluated, and nothing in the loop waits on a table.
 // (A variant that lays (row pair, dword) items out linearly over the lanes to remove the idle lanes of odd level widths
 // measured 258 us against 207 us: vector tap loads, rows split across a wave.)
+#ifndef RR_REVERSE
+#define RR_REVERSE 1
+#endif
 #ifndef RR_WPB
 #define RR_WPB 1   // waves (column strips x row ranges) per block; nothing is shared between them, and one-wave blocks
                    // are placed as soon as any SIMD has room (201 us against 209 with 4)
@@ -298,7 +301,10 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
     const DLevel &S = g.lv[level - 1];
     const int lane = threadIdx.x;
 #if RR_FF
-    const int f = blockIdx.x, bx = blockIdx.y, by = blockIdx.z;
+    // Odd levels walk their row ranges bottom-up: with the frame as the fastest grid index the launch that wrote level l-1
+    // finished with the bottom rows of every frame, and what the memory-side cache still holds of that level is those rows
+    const int f = blockIdx.x, bx = blockIdx.y;
+    const int by = (RR_REVERSE && (level & 1)) ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z;
 #else
     const int f = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
 #endif
