@@ -58,7 +58,7 @@ struct orbx_handle {
     uint32_t *d_lvl_kp = nullptr;
     float *d_lvl_angle = nullptr;
     uint16_t *d_knode = nullptr;
-    int max_cw = 0, max_ch = 0, ncap = 0, lds_keys = 0;
+    int max_cw = 0, max_ch = 0, ncap = 0, lds_keys = 0, lds_keys_few = 0;
     // staging for the host entry points
     uint8_t *st_in[2] = {nullptr, nullptr}; size_t d_in_bytes = 0;
     orbx_keypoint *st_kps[2] = {nullptr, nullptr}; uint8_t *st_desc[2] = {nullptr, nullptr}; int *st_cnt[2] = {nullptr, nullptr};
@@ -240,16 +240,21 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
         // batches, 640x480 / 1000 features: 2794 slots = 4 workgroups per CU 250 us, 1400 slots 204 us, 600 slots 208 us).
         // (Launching the small levels on their own with a node table and key slots sized for them -- more workgroups per CU
         // still -- measured 215-220 us against 200: the second launch boundary costs more than the residency returns.)
+        // Small launches (a few workgroups per CU at most: the single-frame call) have nothing to gain from residency and take
+        // the plan that fills the budget, so that the densest level keeps its keys in LDS too (lds_keys_few).
+        size_t keys_few = 0;
         for (int wg = 4; wg >= 2 && keys == 0; --wg)
-            if (fit_at(wg) >= want) keys = std::max<size_t>(want, 1024);
+            if (fit_at(wg) >= want) { keys = std::max<size_t>(want, 1024); keys_few = fit_at(wg); }
+        h->lds_keys_few = (int)keys_few;
         // large nfeatures (node tables of tens of KB): two workgroups per CU with the dense levels on the global key map beat
         // one workgroup with every level in LDS -- those levels exceed any LDS budget anyway
         if (keys == 0 && fit_at(2) >= 1024) keys = fit_at(2);
         if (keys == 0) keys = fit_at(1);
         if (const char *e = getenv("ORBX_QT_LDS_KEYS")) keys = std::min<size_t>((size_t)std::max(atoi(e), 0), std::min<size_t>(8192, (160 * 1024 - node_part) / 6));
         h->lds_keys = (int)keys;
+        if (getenv("ORBX_QT_LDS_KEYS") || h->lds_keys_few < h->lds_keys) h->lds_keys_few = h->lds_keys;
     }
-    HIPCHK(orbx_quadtree_prepare(orbx_quadtree_smem(h->ncap, h->lds_keys)));
+    HIPCHK(orbx_quadtree_prepare(orbx_quadtree_smem(h->ncap, std::max(h->lds_keys, h->lds_keys_few))));
     // buffers.  Every fill / upload below is issued on the handle's stream: the kernels that read them are launched on
     // the same stream, so the order holds by construction (hipMemset on the NULL stream is asynchronous and NOT ordered
     // with a non-blocking stream -- the round-1 race -- and a device-wide barrier would stall every other handle).
@@ -511,7 +516,7 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
     { ProfScope ps(h, ORBX_K_QUADTREE);
       orbx_launch_quadtree(s, g, B, h->d_dense, h->d_cand_count, h->d_lvl_kp,
                            h->d_lvl_count, d_status, h->d_knode,
-                           h->ncap, h->lds_keys, 0, NL); }
+                           h->ncap, (long long)B * NL >= 1024 ? h->lds_keys : h->lds_keys_few, 0, NL); }
     // orientation (IC_Angle) is computed inside k_describe from the same LDS patch the descriptor uses
     h->blur_valid = false;  // the Gaussian is fused into k_describe; the full blurred image is only built on request
     { ProfScope ps(h, ORBX_K_DESC);
