@@ -239,7 +239,8 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
         // ... and no more than that: key slots beyond `want` only lower the number of workgroups a CU can hold (1024-frame
         // batches, 640x480 / 1000 features: 2794 slots = 4 workgroups per CU 250 us, 1400 slots 204 us, 600 slots 208 us).
         // (Launching the small levels on their own with a node table and key slots sized for them -- more workgroups per CU
-        // still -- measured 215-220 us against 200: the second launch boundary costs more than the residency returns.)
+        // still -- measured 215-220 us against 200, and 277 against 259 us at 1920x1080 / 4000 features where the common plan
+        // admits one workgroup per CU: the large levels set the time, and the second launch boundary is pure cost.)
         // Small launches (a few workgroups per CU at most: the single-frame call) have nothing to gain from residency and take
         // the plan that fills the budget, so that the densest level keeps its keys in LDS too (lds_keys_few).
         size_t keys_few = 0;
