@@ -838,6 +838,441 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_fast_strip: the same per-cell FAST-9/16 + score + NMS + threshold retry as k_fast_rows, reorganised around three pixels
+// per lane (round 3).  k_fast_rows spent 16 wave-instructions per 64-pixel row on the compass pre-test + compaction, ran its
+// ring / score / NMS rounds on the ~210 candidates / ~76 corners of ONE cell pair (64-lane rounds 82 % / 59 % full) and walked
+// every pair of cells as a separate work item.  Here:
+//   * one wave owns a STRIP of up to six horizontally adjacent cells (<= 186 interior columns).  Lane l holds tile columns
+//     3l..3l+2 of the current row as THREE 10-bit fields of one register (lanes 0 and 63 carry the 3-pixel ring margin), the
+//     column window of 7 rows rotates through seven such registers;
+//   * the compass pre-test (a 9-arc of the ring contains one pixel of every opposite pair: for some polarity BOTH pairs
+//     (r0, r8), (r4, r12) must hold a pixel beyond the threshold) is evaluated on the three pixels at once with plain 32-bit
+//     subtractions: field_f(U_k - (U_c + KH)) = 512 + r - c - th - 1 has bit 9 set exactly when r > c + th, fields cannot
+//     borrow from each other (every field stays in [1, 766]), and the horizontal pair r4 / r12 of a lane's three pixels IS the
+//     register of lane + 1 / lane - 1 (DPP wave shifts folded into the subtractions) -- 20 instructions per 186 pixels
+//     instead of 10 per 62.  The shifted operand is always the MINUEND (v_sub_u32_dpp): for the darker polarity the
+//     horizontal pair is tested on the complemented row (255 - pixel per field).  The natural form aL - dpp(C) compiles to
+//     v_subrev_u32_dpp, which on gfx950 returns dpp(src1) - src0, not src1 - dpp(src0) (tools/dpp_probe.hip;
+//     tests/test_abi.py checks that no such instruction is in the code object).  Cells that are switched off (threshold retry, columns beyond the strip) carry th = 255 in their
+//     fields, which no 8-bit difference exceeds;
+//   * ONE compaction per row (ballot of "any of my three pixels") into a list of (row, lane, 3 flags) entries; the entries are
+//     expanded to pixel codes afterwards (wave prefix sum), so the ring test, the score and the NMS run on the merged
+//     candidates of the whole strip in full 64-lane rounds;
+//   * the scores of the corners are kept beside the corner list and scattered into the TILE's own LDS bytes once the last
+//     ring test has read them (no second LDS image: 16 KB per wave instead of 27); a cell that comes out empty (4.6 % of the
+//     cells, reference :1519-1527) has the tile staged again for its minThFAST pass.
+// Candidate list overflow flushes through ring test + score as before; if the corners of a strip do not fit the corner
+// list, the strip falls back to one cell per pass (a cell's corners always fit: the host sizes the list by the largest cell).
+// ------------------------------------------------------------------------------------------------
+#define FS_TP 208             // LDS tile pitch: 13 x 16 bytes >= 192 tile columns + 3 alignment bytes
+#define FS_LOADS 12           // register window of the tile prefetch: 12 loads x 4 rows x 13 pieces of 16 bytes
+#define FS_FMASK 0x20080200u  // bit 9 of the three 10-bit fields
+#define FS_ONES 0x0ff3fcffu   // 255 in each of them
+#ifndef FS_WPS
+#define FS_WPS 2
+#endif
+typedef __attribute__((address_space(3))) uint32_t fs_lds_u32;
+
+struct FsCtx {
+    uint8_t *tile;           // LDS tile, byte (0,0) = sub-mat origin of the strip's first cell; re-used as the score map
+    uint8_t *tile0;          // its 16-byte aligned base (tile = tile0 + (x0 & 3))
+    uint32_t *ent;           // walk output: flags | row << 10 | lane   (ecap entries + one private dummy dword per lane)
+    uint16_t *list;          // candidate codes row << 8 | interior column (lcap); corners compacted in place (bit 15 = brighter ring)
+    uint16_t *corn;          // corners of the pass (ccap)
+    uint8_t *cscore;         // their scores
+    const uint8_t *cellof;   // tile column -> cell ordinal | seam flags (ORBX_STRIP_TILE_COLS)
+    uint2 *ctab;             // per cell: {offx | first interior column << 16, idx_in_level}
+    int *ccapv;              // per cell: slot_cap
+    int *hit;                // per cell: a survivor was seen in this pass
+    int ecap, lcap, ccap, lane;
+};
+
+// full 16-ring test of list[0..n) at threshold th (corners compacted in place to the front of the list), then the score of
+// every corner, appended with its code to the pass's corner list.  Returns false when that list cannot take them.
+__device__ __forceinline__ bool fs_ring_and_score(const FsCtx &c, int n, int th, int &nctot, int dbg_stop) {
+    const int ro[16] = {3 * FS_TP,      3 * FS_TP + 1,  2 * FS_TP + 2,  FS_TP + 3, 3,  -FS_TP + 3,
+                        -2 * FS_TP + 2, -3 * FS_TP + 1, -3 * FS_TP,     -3 * FS_TP - 1, -2 * FS_TP - 2,
+                        -FS_TP - 3,     -3,             FS_TP - 3,      2 * FS_TP - 2,  3 * FS_TP - 1};
+    int ncorn = 0;
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + c.lane;
+        const bool valid = e < n;
+        const uint16_t code = valid ? c.list[e] : (uint16_t)(3 << 8);
+        const uint8_t *ptr = c.tile + (code >> 8) * FS_TP + 3 + (code & 0xff);
+        const int v = ptr[0];
+        const int hi = v + th, lo = v - th;
+        // ring masks by shift-in: mask = 2*mask + (compare) is one v_cmp + one v_addc per ring pixel and polarity
+        uint32_t bright = 0, dark = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int x = ptr[ro[k]];
+            asm("v_cmp_gt_i32 vcc, %2, %3\n\t"
+                "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                "v_cmp_lt_i32 vcc, %2, %4\n\t"
+                "v_addc_co_u32 %1, vcc, %1, %1, vcc"
+                : "+v"(bright), "+v"(dark)
+                : "v"(x), "v"(hi), "v"(lo)
+                : "vcc");
+        }
+        const bool cb = orbx_arc9(bright), cd = orbx_arc9(dark);
+        const bool corner = (int)valid & ((int)cb | (int)cd);
+        const unsigned long long m = orbx_ballot(corner);
+        if (corner) c.list[ncorn + orbx_wave_rank(m)] = (uint16_t)(code | (cb ? 0x8000u : 0u));   // index <= e: already read
+        ncorn += __popcll(m);
+    }
+    orbx_wave_sync();
+    if (nctot + ncorn > c.ccap) return false;
+    if (dbg_stop == 3) { nctot += ncorn; return true; }
+    // score = max over the 16 arcs of the min over the arc of the signed difference, minus 1 (cv::cornerScore<16>), own polarity only
+    for (int e = c.lane; e < ncorn; e += 64) {
+        const uint16_t code = c.list[e];
+        const int off = ((code >> 8) & 0x7f) * FS_TP + 3 + (code & 0xff);
+        const uint8_t *ptr = c.tile + off;
+        const fr_u16 flip = (code & 0x8000u) != 0 ? (fr_u16)0 : (fr_u16)0xff;
+        const fr_i16 v = (fr_i16)((fr_u16)ptr[0] ^ flip);
+        fr_i16 d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = (fr_i16)((fr_i16)((fr_u16)ptr[ro[k]] ^ flip) - v);
+        fr_i16 a0 = (fr_i16)th;
+        fr_i16 m2[16], m4[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m2[k] = fr_smin(d[k], d[(k + 1) & 15]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m4[k] = fr_smin(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a0 = fr_smax(a0, fr_smin(fr_smin(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
+        c.corn[nctot + e] = (uint16_t)(code & 0x7fffu);
+        c.cscore[nctot + e] = (uint8_t)(a0 - 1);
+    }
+    nctot += ncorn;
+    orbx_wave_sync();
+    return true;
+}
+
+struct FsOut {
+    uint2 *out;      // dense candidate array of this (frame, level)
+    int *cursor;     // its fill count
+    int out_cap;
+    int offy;        // i * hCell of the strip's cell row
+};
+
+// strict 3x3 NMS of the pass's corners among the corners of the SAME cell; the score map is built in the tile's bytes
+// (every ring test of the pass has been made).  Survivors go straight to the level's dense key array.
+__device__ __forceinline__ void fs_nms(const FsCtx &c, const FsOut &go, int n, int th_rows, bool capped, int ncell, int *status_f) {
+    for (int i = c.lane; i < th_rows * (FS_TP / 16); i += 64) ((uint4 *)c.tile0)[i] = make_uint4(0, 0, 0, 0);
+    orbx_wave_sync();
+    for (int e = c.lane; e < n; e += 64) {
+        const uint16_t code = c.corn[e];
+        c.tile[(code >> 8) * FS_TP + 3 + (code & 0xff)] = c.cscore[e];
+    }
+    orbx_wave_sync();
+    int nsk[ORBX_STRIP_MAXCELLS];
+#pragma unroll
+    for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) nsk[k] = 0;
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + c.lane;
+        const bool valid = e < n;
+        const uint16_t code = valid ? c.corn[e] : (uint16_t)(3 << 8);
+        const int col = code & 0xff, ly = code >> 8;
+        const uint8_t *sp = c.tile + ly * FS_TP + 3 + col;
+        const int sc = sp[0];
+        int l0 = sp[-FS_TP - 1], l1 = sp[-1], l2 = sp[FS_TP - 1];
+        int r0 = sp[-FS_TP + 1], r1 = sp[1], r2 = sp[FS_TP + 1];
+        const int u = sp[-FS_TP], dn = sp[FS_TP];
+        const int cf = c.cellof[3 + col];
+        const int kc = cf & 7;
+        // the score map is shared by the cells of the strip: the neighbours across a seam belong to another cv::FAST call
+        const bool seam_l = (cf & 0x40) != 0, seam_r = (cf & 0x80) != 0;
+        l0 = seam_l ? 0 : l0; l1 = seam_l ? 0 : l1; l2 = seam_l ? 0 : l2;
+        r0 = seam_r ? 0 : r0; r1 = seam_r ? 0 : r1; r2 = seam_r ? 0 : r2;
+        const bool keep = (int)valid & (int)(sc > l0) & (int)(sc > l1) & (int)(sc > l2) & (int)(sc > r0) & (int)(sc > r1) &
+                          (int)(sc > r2) & (int)(sc > u) & (int)(sc > dn);
+        bool ok = keep;
+        if (capped) {   // max_cand_per_cell cut the exact NMS worst case: a cell reports its first slot_cap survivors (emission order)
+            int slot = 0;
+#pragma unroll
+            for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) {
+                const unsigned long long mk = orbx_ballot(keep && kc == k);
+                if (kc == k) slot = nsk[k] + orbx_wave_rank(mk);
+                nsk[k] += __popcll(mk);
+            }
+            ok = keep && slot < c.ccapv[kc];
+        }
+        const unsigned long long mok = orbx_ballot(ok);
+        if (orbx_ballot(keep) != 0ull) {
+            if (keep) c.hit[kc] = 1;
+            int base = 0;
+            if (c.lane == 0 && mok != 0ull) base = atomicAdd(go.cursor, (int)__popcll(mok));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int pos = base + orbx_wave_rank(mok);
+            if (ok && pos < go.out_cap) {
+                const uint2 ct = c.ctab[kc];
+                const int lx = 3 + col - (int)(ct.x >> 16);
+                uint2 o;
+                o.x = (uint32_t)(lx + (int)(ct.x & 0xffffu)) | ((uint32_t)(ly + go.offy) << 12) | ((uint32_t)sc << 24);
+                o.y = (ct.y << 12) | ((uint32_t)ly << 6) | (uint32_t)lx;   // emission order key
+                go.out[pos] = o;
+            }
+        }
+    }
+    if (capped) {   // more survivors than a cell may report: reported, not silent
+        bool over = false;
+#pragma unroll
+        for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) over = over || (k < ncell && nsk[k] > c.ccapv[k]);
+        if (over && c.lane == 0) atomicMax(status_f, (int)ORBX_CAPACITY);
+    }
+    orbx_wave_sync();
+}
+
+__global__ __launch_bounds__(64, FS_WPS) void k_fast_strip(DGeom g, const OrbxCell *__restrict__ cells,
+                                                           const OrbxFastGroup *__restrict__ strips,
+                                                           const uint8_t *__restrict__ strip_cellof,
+                                                           const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
+                                                           int *__restrict__ cand_cursor, int *__restrict__ status, int rows,
+                                                           int ecap, int lcap, int ccap, int nstrips, int spw, int capped,
+                                                           int dbg_stop) {
+    // dbg_stop (ORBX_FAST_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS; results are wrong unless 0): 1 = after
+    // staging, 2 = after the pre-test walk, 3 = after the ring test, 4 = before NMS.  The shipped library pins it to 0.
+#ifndef ORBX_TIMING_KNOBS
+    dbg_stop = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
+    // tile[rows*TP] | ent u32[ecap + 64] | list u16[lcap] | corn u16[ccap] | cscore u8[ccap] | cellof u8[192] | ctab uint2[8] | ccapv int[8] | hit int[8]
+    uint8_t *s_tile = fast_smem;
+    uint32_t *s_ent = (uint32_t *)(s_tile + rows * FS_TP);
+    uint16_t *s_list = (uint16_t *)(s_ent + ecap + 64);
+    uint16_t *s_corn = s_list + lcap;
+    uint8_t *s_cscore = (uint8_t *)(s_corn + ccap);
+    uint8_t *s_cellof = s_cscore + ccap;
+    uint2 *s_ctab = (uint2 *)(s_cellof + ORBX_STRIP_TILE_COLS);
+    int *s_ccapv = (int *)(s_ctab + 8);
+    int *s_hit = s_ccapv + 8;
+    const int lane = threadIdx.x;
+    const int f = blockIdx.x;   // frame fastest: all strips of one frame share one XCD's L2
+    const int g0 = blockIdx.y * spw;
+    const int ng = min(spw, nstrips - g0);
+    // staging: a lane loads 16 bytes, 13 lanes cover a tile row (208 bytes), 4 rows per load, FS_LOADS loads = 48 rows in
+    // registers.  Row offsets are 32-bit adds from the first row's offset, clamped to the strip's last row; the piece offset
+    // is clamped to the level's last 16 bytes of a row (pieces beyond the level's width hold columns no cell reaches).
+    const int rq = (lane * 5) >> 6, dq = lane - 13 * rq;   // lane / 13, lane % 13  (lanes 52..63: rq = 4, idle)
+    // (twelve named registers, not an array: the array form of this window ends up in scratch memory)
+#define FS_FOR_LOADS(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
+    static_assert(FS_LOADS == 12, "FS_FOR_LOADS lists the loads");
+#define FS_DECL(k) uint4 tv##k;
+    FS_FOR_LOADS(FS_DECL)
+#undef FS_DECL
+    uint32_t tcf = 0;
+    OrbxFastGroup grp_n = strips[g0];
+    OrbxCell c0_n = cells[grp_n.cell0];
+    const uint8_t *fbase = pyr + (long long)f * g.pyr_bytes;
+#define FS_ROW_OFFSETS(CELL, LV, o, olast, vpitch4)                                                                        \
+        uint32_t vpitch4 = (uint32_t)(4 * LV.pitch);                                                                      \
+        asm("" : "+v"(vpitch4));   /* in a VGPR: a VOP2 add with an SGPR source issues at the slow rate */                  \
+        const uint32_t xoff_ = (uint32_t)min((CELL.x0 & ~3) + 16 * dq, LV.pitch - 16);                                    \
+        const uint32_t olast = (uint32_t)__mul24((int)CELL.y0 + (int)CELL.ch - 1, LV.pitch) + xoff_;                      \
+        uint32_t o = (uint32_t)__mul24((int)CELL.y0 + min(rq, 3), LV.pitch) + xoff_;
+#define FS_LOAD1(k) tv##k = *(const uint4 *)(srcn + min(o, olast)); o += vpitch4;
+#define FS_PREFETCH()                                                                                                     \
+    {                                                                                                                     \
+        const DLevel &Ln = g.lv[c0_n.level];                                                                             \
+        const uint8_t *srcn = fbase + Ln.off;                                                                             \
+        FS_ROW_OFFSETS(c0_n, Ln, o, olast, vpitch4)                                                                       \
+        FS_FOR_LOADS(FS_LOAD1)                                                                                            \
+        tcf = ((const uint32_t *)strip_cellof)[(size_t)(g0 + gi_n) * (ORBX_STRIP_TILE_COLS / 4) + min(lane, ORBX_STRIP_TILE_COLS / 4 - 1)]; \
+    }
+    int gi_n = 0;
+    FS_PREFETCH()
+  for (int gi = 0; gi < ng; ++gi) {
+    const OrbxFastGroup grp = grp_n;
+    const OrbxCell c0 = c0_n;
+    const DLevel &L = g.lv[c0.level];
+    const int th_rows = c0.ch;
+    const int ncell = grp.ncell;
+    // ---- stage the tile: prefetched registers -> LDS; per-cell tables
+    {
+        uint8_t *trow = s_tile + rq * FS_TP + 16 * dq;
+#define FS_STORE1(k) if (rq < 4 && 4 * k + rq < th_rows) *(uint4 *)(trow + 4 * k * FS_TP) = tv##k;
+        FS_FOR_LOADS(FS_STORE1)
+#undef FS_STORE1
+        if (th_rows > 4 * FS_LOADS) {   // cells taller than the register window (tiny pyramid levels only)
+            const uint8_t *src = fbase + L.off;
+            FS_ROW_OFFSETS(c0, L, o, olast, vpitch4)
+            o += (uint32_t)FS_LOADS * vpitch4;
+            for (int r = 4 * FS_LOADS + rq; r < th_rows; r += 4) {
+                if (rq < 4) *(uint4 *)(s_tile + r * FS_TP + 16 * dq) = *(const uint4 *)(src + min(o, olast));
+                o += vpitch4;
+            }
+        }
+        if (lane < ORBX_STRIP_TILE_COLS / 4) ((uint32_t *)s_cellof)[lane] = tcf;
+        if (lane < ncell) {
+            const OrbxCell cj = cells[grp.cell0 + lane];
+            s_ctab[lane] = make_uint2((uint32_t)(uint16_t)cj.offx | ((uint32_t)(cj.x0 - c0.x0) << 16), (uint32_t)cj.idx_in_level);
+            s_ccapv[lane] = cj.slot_cap;
+        }
+    }
+    if (gi + 1 < ng) {
+        gi_n = gi + 1;
+        grp_n = strips[g0 + gi_n];
+        c0_n = cells[grp_n.cell0];
+        FS_PREFETCH()
+    }
+    FsCtx cx;
+    cx.tile = s_tile + (c0.x0 & 3);
+    cx.tile0 = s_tile;
+    cx.ent = s_ent; cx.list = s_list; cx.corn = s_corn; cx.cscore = s_cscore; cx.cellof = s_cellof;
+    cx.ctab = s_ctab; cx.ccapv = s_ccapv; cx.hit = s_hit;
+    cx.ecap = ecap; cx.lcap = lcap; cx.ccap = ccap; cx.lane = lane;
+    FsOut go;
+    go.out = cand + (long long)f * g.cand_total + L.cand_begin;
+    go.cursor = cand_cursor + f * g.nlevels + c0.level;
+    go.out_cap = L.cand_cap;
+    go.offy = c0.offy;
+    orbx_wave_sync();
+    if (dbg_stop == 1) continue;
+    const bool two_th = g.min_th != g.ini_th;
+    const int yend = th_rows - 3;
+    const uint8_t *pc = cx.tile + 3 * lane;                  // this lane's three columns, row 0
+    unsigned act_ini = (1u << ncell) - 1u, act_min = 0u;     // cells still to be detected at iniThFAST / minThFAST
+    bool tile_ok = true, single = false;
+    while ((act_ini | act_min) != 0u) {
+        const unsigned pool = act_ini != 0u ? act_ini : act_min;
+        const int th = act_ini != 0u ? g.ini_th : g.min_th;
+        const unsigned act = single ? (pool & (0u - pool)) : pool;   // after a corner-list overflow: one cell per pass
+        if (!tile_ok) {   // the last pass's NMS turned the tile into its score map: stage it again (L2 hit)
+            const uint8_t *src = fbase + L.off;
+            FS_ROW_OFFSETS(c0, L, o, olast, vpitch4)
+            for (int r = rq; r < th_rows; r += 4) {
+                if (rq < 4) *(uint4 *)(s_tile + r * FS_TP + 16 * dq) = *(const uint4 *)(src + min(o, olast));
+                o += vpitch4;
+            }
+            tile_ok = true;
+            orbx_wave_sync();
+        }
+        // per-lane threshold constants: a field whose column is outside the strip or in a cell that is not part of this pass
+        // carries th = 255 (no 8-bit difference exceeds it): the pre-test needs no lane or column mask
+        uint32_t KH = 0, KL = 0;
+#pragma unroll
+        for (int fq = 0; fq < 3; ++fq) {
+            const int kc = s_cellof[3 * lane + fq] & 7;
+            const int thf = ((act >> kc) & 1u) ? th : 255;
+            KH += (uint32_t)(thf + 1 - 512) << (10 * fq);
+            KL += (uint32_t)(511 - thf) << (10 * fq);
+        }
+        int nctot = 0;
+        bool overflow = false;
+        int y = 3;
+        const uint32_t ent0 = (uint32_t)(uintptr_t)(fs_lds_u32 *)s_ent;
+        const uint32_t dummy = ent0 + 4u * (uint32_t)ecap + 4u * (uint32_t)lane;
+        while (y < yend && !overflow) {
+            // ---- compass pre-test, one row per step, three pixels per lane (see the header)
+            const uint8_t *pr = pc + y * FS_TP;
+#define FS_PACK(p) ((uint32_t)(p)[0] | ((uint32_t)(p)[1] << 10) | ((uint32_t)(p)[2] << 20))
+            uint32_t w0 = FS_PACK(pr - 3 * FS_TP), w1 = FS_PACK(pr - 2 * FS_TP), w2 = FS_PACK(pr - FS_TP), w3 = FS_PACK(pr),
+                     w4 = FS_PACK(pr + FS_TP), w5 = FS_PACK(pr + 2 * FS_TP), w6;
+            uint32_t nb = ent0;
+            uint32_t code = (uint32_t)((y << 10) | lane);
+            // software-pipelined: the three LDS bytes of row y+4 are requested before row y is evaluated; the row after the
+            // last one is read but never used (it lies inside the LDS allocation)
+            uint32_t nx0 = pr[3 * FS_TP], nx1 = pr[3 * FS_TP + 1], nx2 = pr[3 * FS_TP + 2];
+#define FS_STEP(R8, C, R0)                                                                                              \
+            {                                                                                                           \
+                R0 = nx0 | (nx1 << 10) | (nx2 << 20);                                                                   \
+                pr += FS_TP;                                                                                            \
+                nx0 = pr[3 * FS_TP]; nx1 = pr[3 * FS_TP + 1]; nx2 = pr[3 * FS_TP + 2];                                  \
+                asm("" : "+v"(nx0), "+v"(nx1), "+v"(nx2));                                                              \
+                const uint32_t aH = C + KH, aL = C + KL;                                                                \
+                const uint32_t vc = FS_ONES - C, aV = vc + KH;   /* the row complemented: darker = brighter there */     \
+                const uint32_t cr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xf, 0xf, true);            \
+                const uint32_t cl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xf, 0xf, true);            \
+                const uint32_t vr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vc, 0x130, 0xf, 0xf, true);           \
+                const uint32_t vl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vc, 0x138, 0xf, 0xf, true);           \
+                const uint32_t bb = ((R0 - aH) | (R8 - aH)) & ((cr - aH) | (cl - aH));                                  \
+                const uint32_t dd = ((aL - R0) | (aL - R8)) & ((vr - aV) | (vl - aV));                                  \
+                const uint32_t cc = (bb | dd) & FS_FMASK;                                                               \
+                const bool cnd = cc != 0u;                                                                              \
+                const unsigned long long m = orbx_ballot(cnd);                                                          \
+                *(fs_lds_u32 *)(uintptr_t)(cnd ? nb + 4u * (uint32_t)orbx_wave_rank(m) : dummy) = cc | code;            \
+                nb += 4u * (uint32_t)__popcll(m);                                                                       \
+                code += 0x400u;                                                                                         \
+            }
+            while (y + 7 <= yend && nb + 7u * 256u <= ent0 + 4u * (uint32_t)ecap) {
+                FS_STEP(w0, w3, w6)
+                FS_STEP(w1, w4, w0)
+                FS_STEP(w2, w5, w1)
+                FS_STEP(w3, w6, w2)
+                FS_STEP(w4, w0, w3)
+                FS_STEP(w5, w1, w4)
+                FS_STEP(w6, w2, w5)
+                y += 7;
+            }
+            while (y < yend && nb + 256u <= ent0 + 4u * (uint32_t)ecap) {
+                FS_STEP(w0, w3, w6)
+                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6;
+                ++y;
+            }
+#undef FS_STEP
+#undef FS_PACK
+            const int ne = (int)((nb - ent0) >> 2);
+            orbx_wave_sync();
+            if (dbg_stop == 2) { if (ne == 12345) cand_cursor[0] = ne; continue; }
+            // ---- entries -> pixel codes (order kept: row-major over the strip), ring test + score in full rounds
+            int nl = 0;
+            for (int e0 = 0; e0 < ne && !overflow; e0 += 64) {
+                if (nl + 192 > lcap) {
+                    overflow = !fs_ring_and_score(cx, nl, th, nctot, dbg_stop);
+                    nl = 0;
+                    if (overflow) break;
+                }
+                const int e = e0 + lane;
+                const uint32_t en = e < ne ? s_ent[e] : 0u;
+                const int f0 = (en >> 9) & 1, f1 = (en >> 19) & 1, f2 = (en >> 29) & 1;
+                const int cnt = f0 + f1 + f2;
+                const int incl = orbx_wave_scan(cnt);
+                const int tot = __builtin_amdgcn_readlane(incl, 63);
+                const uint32_t cb = (((en >> 10) & 0x7fu) << 8) + 3u * (en & 63u) - 3u;
+                uint16_t *lp = s_list + nl + incl - cnt;
+                if (f0) { *lp = (uint16_t)cb; ++lp; }
+                if (f1) { *lp = (uint16_t)(cb + 1u); ++lp; }
+                if (f2) { *lp = (uint16_t)(cb + 2u); }
+                nl += tot;
+            }
+            orbx_wave_sync();
+            if (!overflow && nl > 0) overflow = !fs_ring_and_score(cx, nl, th, nctot, dbg_stop);
+        }
+        if (overflow) {
+            if ((act & (act - 1u)) == 0u) {   // a single cell's corners always fit (host: ccap >= largest cell interior)
+                if (lane == 0) atomicMax(&status[f], (int)ORBX_CAPACITY);
+                act_ini &= ~act; act_min &= ~act;
+            }
+            single = true;
+            continue;   // the tile is intact: NMS has not run
+        }
+        if (lane < ORBX_STRIP_MAXCELLS) s_hit[lane] = 0;
+        if (dbg_stop >= 2) {
+            if (lane < ORBX_STRIP_MAXCELLS) s_hit[lane] = 1;
+            orbx_wave_sync();
+        } else {
+            fs_nms(cx, go, nctot, th_rows, capped != 0, ncell, &status[f]);
+            tile_ok = false;
+        }
+        unsigned hits = 0u;
+#pragma unroll
+        for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) hits |= (k < ncell && s_hit[k] != 0) ? (1u << k) : 0u;
+        hits = (unsigned)__builtin_amdgcn_readfirstlane((int)hits);   // (wave-uniform by construction: keeps the pass loop scalar)
+        // vKeysCell.empty() -> that cell alone repeats with minThFAST (:1519-1527)
+        if (act_ini != 0u) { act_ini &= ~act; if (two_th) act_min |= act & ~hits; }
+        else act_min &= ~act;
+        orbx_wave_sync();
+    }
+    orbx_wave_sync();   // the next strip overwrites tile / lists / tables
+  }
+#undef FS_PREFETCH
+#undef FS_LOAD1
+#undef FS_FOR_LOADS
+#undef FS_ROW_OFFSETS
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3: DistributeOctTree (reference src/ORBextractor.cc:1050-1417) -- one workgroup per (frame, level).
 //
 // The reference mutates a std::list sequentially; its observable result (which nodes exist, their list
@@ -2418,6 +2853,22 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
     const int gpw = (long long)B * ngroups >= 16384 ? FR_GPW : 1;
     hipLaunchKernelGGL(k_fast_rows, dim3(B, (ngroups + gpw - 1) / gpw), dim3(64), smem, s, g, cells, groups, pyr, cand,
                        cand_cursor, status, max_ch, lcap, ngroups, gpw, dbg_stop);
+}
+void orbx_launch_fast_strip(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *strips,
+                            const uint8_t *strip_cellof, int nstrips, const uint8_t *pyr, uint2 *cand, int *cand_cursor,
+                            int *status, int max_ch, int ecap, int lcap, int ccap, int capped, int dbg_stop) {
+    if (nstrips <= 0) return;
+    ecap = (max(ecap, 64) + 1) & ~1;
+    lcap = (max(lcap, 192) + 3) & ~3;
+    ccap = (max(ccap, 64) + 7) & ~7;
+    max_ch = (max_ch + 3) & ~3;
+    const size_t smem = (size_t)max_ch * FS_TP + (size_t)4 * (ecap + 64) + (size_t)2 * lcap + (size_t)3 * ccap +
+                        ORBX_STRIP_TILE_COLS + 8 * sizeof(uint2) + 16 * sizeof(int);
+    // strips per wave: 2 when the launch has waves to spare (the second strip's tile is prefetched while the first is
+    // processed); one per wave for small batches, where the serial length of a wave is what the caller waits for
+    const int spw = (long long)B * nstrips >= 8192 ? 2 : 1;
+    hipLaunchKernelGGL(k_fast_strip, dim3(B, (nstrips + spw - 1) / spw), dim3(64), smem, s, g, cells, strips, strip_cellof, pyr,
+                       cand, cand_cursor, status, max_ch, ecap, lcap, ccap, nstrips, spw, capped, dbg_stop);
 }
 void orbx_launch_undistort(hipStream_t s, int B, int max_n, int cap, const double *K4, const double *k14, int identity,
                            const orbx_keypoint *kps, const int *counts, orbx_keypoint *out) {
