@@ -17,6 +17,10 @@ void Frame::ComputeStereoMatches()
 {
     mvuRight = std::vector<float>(N, -1.0f);
     mvDepth = std::vector<float>(N, -1.0f);
+    // nothing below reads mvImagePyramid: the extractors can stop copying the eight levels back after every frame
+    // (compat/ORBextractor.h copies them by default so that the header alone stays a drop-in)
+    mpORBextractorLeft->SetEagerPyramid(false);
+    mpORBextractorRight->SetEagerPyramid(false);
     if (N == 0) return;
     static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint must be the 28-byte POD");
     int nmatches = 0;

@@ -58,16 +58,18 @@ public:
             const cv::KeyPoint *src = reinterpret_cast<const cv::KeyPoint *>(kps.data());
             keypoints.insert(keypoints.end(), src, src + n);
         }
-        // mvImagePyramid is public, but its only reader is Frame::ComputeStereoMatches (src/Frame.cc:910,1040,1072,1079), whose
-        // body compat/Frame_stereo.inl replaces by orbx_stereo_match (the pyramids stay on the device).  The eight levels
-        // (1.16 MB at 640x480) are therefore NOT copied per call; FetchPyramid() fills the member on demand.
+        // mvImagePyramid is public and Frame::ComputeStereoMatches reads it right after ExtractORB (src/Frame.cc:910,1040,
+        // 1072,1079), so by default the eight levels are copied back after every call: swapping in this header ALONE stays a
+        // drop-in.  An integration that also applies compat/Frame_stereo.inl (orbx_stereo_match: the pyramids stay on the
+        // device) turns the copy off with SetEagerPyramid(false) -- the .inl does it on first use -- and saves 1.16 MB of
+        // device-to-host traffic per 640x480 frame; FetchPyramid() then fills the member on demand.
         pyramid_stale_ = true;
         if (eager_pyramid_) FetchPyramid();
     }
 
     // Fills mvImagePyramid with the padded levels of the last frame (fork semantics, src/ORBextractor.cc:2165-2166).  For a
-    // caller that keeps the reference's own ComputeStereoMatches: call it on both extractors before that function, or
-    // construct the extractors with SetEagerPyramid(true).
+    // caller that keeps the reference's own ComputeStereoMatches nothing needs doing (eager copy is the default); after
+    // SetEagerPyramid(false) call it on both extractors before anything reads mvImagePyramid.
     void FetchPyramid() {
         if (!pyramid_stale_) return;
         for (int l = 0; l < nlevels_; ++l) {
@@ -94,7 +96,7 @@ public:
 protected:
     orbx_handle *h_ = nullptr;
     int nlevels_ = 0;
-    bool pyramid_stale_ = true, eager_pyramid_ = false;
+    bool pyramid_stale_ = true, eager_pyramid_ = true;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
 

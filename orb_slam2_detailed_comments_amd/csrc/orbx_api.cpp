@@ -52,7 +52,7 @@ struct orbx_handle {
     OrbxFastGroup *d_strips = nullptr;      // k_fast_strip work items
     uint8_t *d_cellof = nullptr;            // their column -> cell tables
     bool fast_rows = false;                 // ORBX_FAST_IMPL=rows: round-2 kernel (A/B runs during development)
-    int fast_ecap = 512, fast_lcap2 = 1024, fast_ccap = 1024;   // LDS list capacities of k_fast_strip
+    int fast_ecap = 384, fast_lcap2 = 512, fast_ccap = 576, fast_bh = 16;   // LDS list capacities / band height of k_fast_strip
     bool resize_legacy = false;   // ORBX_RESIZE_IMPL=legacy: k_pyr_resize for every level (A/B runs)
     int fast_stop = 0;      // ORBX_FAST_STOP: only read in -DORBX_TIMING_KNOBS builds
     int fast_lcap = 640;    // LDS work-list entries of k_fast_rows (ORBX_FAST_LCAP; tests shrink it to force the flush paths)
@@ -272,13 +272,13 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
 #endif
     if (const char *e = getenv("ORBX_FAST_LCAP")) h->fast_lcap = std::max(64, atoi(e));
     if (const char *e = getenv("ORBX_FAST_IMPL")) h->fast_rows = strcmp(e, "rows") == 0;
-    // k_fast_strip: the corner list must take the corners of the largest single cell (the fallback of a strip whose corners
-    // overflow is one cell per pass); ORBX_FAST_LCAP shrinks all three lists to force the flush / fallback paths (tests)
-    h->fast_ecap = 512; h->fast_lcap2 = 1024; h->fast_ccap = std::max(1024, h->geom.max_cell_interior);
-    if (const char *e = getenv("ORBX_FAST_LCAP")) {
-        const int v = std::max(64, atoi(e));
-        h->fast_ecap = v; h->fast_lcap2 = std::max(192, v); h->fast_ccap = std::max(v, h->geom.max_cell_interior);
-    }
+    // k_fast_strip: ORBX_FAST_LCAP shrinks the three LDS lists to force the flush / band-splitting paths (tests; the launcher keeps
+    // the corner list >= three strip rows), ORBX_FAST_BH sets the band height (A/B runs)
+    h->fast_ecap = 384; h->fast_lcap2 = 512; h->fast_ccap = 576; h->fast_bh = 16;
+    if (const char *e = getenv("ORBX_FAST_LCAP")) { const int v = std::max(64, atoi(e)); h->fast_ecap = v; h->fast_lcap2 = v; h->fast_ccap = v; }
+    if (const char *e = getenv("ORBX_FAST_BH")) h->fast_bh = std::max(1, atoi(e));
+    if (const char *e = getenv("ORBX_FAST_ECAP")) h->fast_ecap = std::max(64, atoi(e));
+    if (const char *e = getenv("ORBX_FAST_CCAP")) h->fast_ccap = std::max(64, atoi(e));
     const OrbxGeom &hg = h->geom;
     hipStream_t s = h->stream;
     // Optional fork of the batched launch sequence (run_chunk): ORBX_FORK_LEVEL = l > 0 resizes levels >= l and runs their
@@ -511,7 +511,7 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
                                   h->max_ch, h->fast_lcap, h->fast_stop);
         else
             orbx_launch_fast_strip(st, g, B, h->d_cells, h->d_strips + first, h->d_cellof + (size_t)first * ORBX_STRIP_TILE_COLS, count,
-                                   h->d_pyr, h->d_dense, h->d_cand_count, d_status, h->max_ch, h->fast_ecap, h->fast_lcap2,
+                                   h->d_pyr, h->d_dense, h->d_cand_count, d_status, h->fast_bh, h->fast_ecap, h->fast_lcap2,
                                    h->fast_ccap, capped, h->fast_stop);
     };
     const bool fork = h->fork_level > 0 && (long long)B * ngroups >= 16384;

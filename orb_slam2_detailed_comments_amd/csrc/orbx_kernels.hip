@@ -695,7 +695,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     gc.out_cap = L.cand_cap;
     orbx_wave_sync();
     if (dbg_stop == 1) continue;
-    const bool two_th = g.min_th != g.ini_th;
+    const bool two_th = g.min_th != g.ini_th && dbg_stop != 5;   // (5: timing build, no threshold retry)
     const bool colv = lane < niw;
     const bool second = lane >= iw0;
     const uint8_t *pc = cx.tile + 3 + (colv ? lane : 0);   // this lane's column, row 0
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         }
         // ---- NMS
         int a0 = 0, a1 = 0;
-        if (dbg_stop >= 2) { a0 = a1 = 1; } else
+        if (dbg_stop >= 2 && dbg_stop != 5) { a0 = a1 = 1; } else
         if (!overflow) {
             fr_nms(cx, gc, s_corn, nctot, a0, a1);
         } else {
@@ -864,12 +864,14 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
 // Candidate list overflow flushes through ring test + score as before; if the corners of a strip do not fit the corner
 // list, the strip falls back to one cell per pass (a cell's corners always fit: the host sizes the list by the largest cell).
 // ------------------------------------------------------------------------------------------------
+#ifndef FS_TP
 #define FS_TP 208             // LDS tile pitch: 13 x 16 bytes >= 192 tile columns + 3 alignment bytes
-#define FS_LOADS 12           // register window of the tile prefetch: 12 loads x 4 rows x 13 pieces of 16 bytes
+#endif
+#define FS_LOADS 6            // register window of the tile prefetch: 6 loads x 4 rows x 13 pieces of 16 bytes = one band
 #define FS_FMASK 0x20080200u  // bit 9 of the three 10-bit fields
 #define FS_ONES 0x0ff3fcffu   // 255 in each of them
 #ifndef FS_WPS
-#define FS_WPS 2
+#define FS_WPS 4
 #endif
 typedef __attribute__((address_space(3))) uint32_t fs_lds_u32;
 
@@ -956,25 +958,24 @@ struct FsOut {
     int offy;        // i * hCell of the strip's cell row
 };
 
-// strict 3x3 NMS of the pass's corners among the corners of the SAME cell; the score map is built in the tile's bytes
-// (every ring test of the pass has been made).  Survivors go straight to the level's dense key array.
-__device__ __forceinline__ void fs_nms(const FsCtx &c, const FsOut &go, int n, int th_rows, bool capped, int ncell, int *status_f) {
-    for (int i = c.lane; i < th_rows * (FS_TP / 16); i += 64) ((uint4 *)c.tile0)[i] = make_uint4(0, 0, 0, 0);
+// strict 3x3 NMS of corn[0..n) among the corners of the SAME cell; the score map is built in the band tile's bytes (every ring
+// test of the band has been made).  Only corners of tile rows [rlo, rhi) are decided here (the rows below belong to the next
+// band: their lower neighbours are not known yet); survivors go straight to the level's dense key array.
+__device__ __forceinline__ void fs_nms(const FsCtx &c, const FsOut &go, int n, int tile_rows, int rlo, int rhi, int yoff,
+                                       bool capped, int *nsk) {
+    for (int i = c.lane; i < (tile_rows * FS_TP + 15) / 16; i += 64) ((uint4 *)c.tile0)[i] = make_uint4(0, 0, 0, 0);
     orbx_wave_sync();
     for (int e = c.lane; e < n; e += 64) {
         const uint16_t code = c.corn[e];
         c.tile[(code >> 8) * FS_TP + 3 + (code & 0xff)] = c.cscore[e];
     }
     orbx_wave_sync();
-    int nsk[ORBX_STRIP_MAXCELLS];
-#pragma unroll
-    for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) nsk[k] = 0;
     for (int e0 = 0; e0 < n; e0 += 64) {
         const int e = e0 + c.lane;
-        const bool valid = e < n;
-        const uint16_t code = valid ? c.corn[e] : (uint16_t)(3 << 8);
-        const int col = code & 0xff, ly = code >> 8;
-        const uint8_t *sp = c.tile + ly * FS_TP + 3 + col;
+        const uint16_t code = e < n ? c.corn[e] : (uint16_t)(3 << 8);
+        const int col = code & 0xff, lr = code >> 8;
+        const bool valid = e < n && lr >= rlo && lr < rhi;
+        const uint8_t *sp = c.tile + lr * FS_TP + 3 + col;
         const int sc = sp[0];
         int l0 = sp[-FS_TP - 1], l1 = sp[-1], l2 = sp[FS_TP - 1];
         int r0 = sp[-FS_TP + 1], r1 = sp[1], r2 = sp[FS_TP + 1];
@@ -1007,19 +1008,13 @@ __device__ __forceinline__ void fs_nms(const FsCtx &c, const FsOut &go, int n, i
             const int pos = base + orbx_wave_rank(mok);
             if (ok && pos < go.out_cap) {
                 const uint2 ct = c.ctab[kc];
-                const int lx = 3 + col - (int)(ct.x >> 16);
+                const int lx = 3 + col - (int)(ct.x >> 16), ly = lr + yoff;
                 uint2 o;
                 o.x = (uint32_t)(lx + (int)(ct.x & 0xffffu)) | ((uint32_t)(ly + go.offy) << 12) | ((uint32_t)sc << 24);
                 o.y = (ct.y << 12) | ((uint32_t)ly << 6) | (uint32_t)lx;   // emission order key
                 go.out[pos] = o;
             }
         }
-    }
-    if (capped) {   // more survivors than a cell may report: reported, not silent
-        bool over = false;
-#pragma unroll
-        for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) over = over || (k < ncell && nsk[k] > c.ccapv[k]);
-        if (over && c.lane == 0) atomicMax(status_f, (int)ORBX_CAPACITY);
     }
     orbx_wave_sync();
 }
@@ -1029,8 +1024,8 @@ __global__ __launch_bounds__(64, FS_WPS) void k_fast_strip(DGeom g, const OrbxCe
                                                            const uint8_t *__restrict__ strip_cellof,
                                                            const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
                                                            int *__restrict__ cand_cursor, int *__restrict__ status, int rows,
-                                                           int ecap, int lcap, int ccap, int nstrips, int spw, int capped,
-                                                           int dbg_stop) {
+                                                           int bhmax, int ecap, int lcap, int ccap, int nstrips, int spw,
+                                                           int capped, int dbg_stop) {
     // dbg_stop (ORBX_FAST_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS; results are wrong unless 0): 1 = after
     // staging, 2 = after the pre-test walk, 3 = after the ring test, 4 = before NMS.  The shipped library pins it to 0.
 #ifndef ORBX_TIMING_KNOBS
@@ -1051,71 +1046,66 @@ __global__ __launch_bounds__(64, FS_WPS) void k_fast_strip(DGeom g, const OrbxCe
     const int f = blockIdx.x;   // frame fastest: all strips of one frame share one XCD's L2
     const int g0 = blockIdx.y * spw;
     const int ng = min(spw, nstrips - g0);
-    // staging: a lane loads 16 bytes, 13 lanes cover a tile row (208 bytes), 4 rows per load, FS_LOADS loads = 48 rows in
-    // registers.  Row offsets are 32-bit adds from the first row's offset, clamped to the strip's last row; the piece offset
-    // is clamped to the level's last 16 bytes of a row (pieces beyond the level's width hold columns no cell reaches).
+    // A strip is walked in BANDS of at most bhmax interior rows (tile = band + 6 ring rows <= `rows`): the LDS footprint of a wave
+    // is a third of the whole strip's, which is what buys the kernel its waves per CU.  Staging: a lane loads 16 bytes, 13 lanes
+    // cover a tile row (208 bytes), 4 rows per load, FS_LOADS loads = 24 rows in registers (the NEXT band's, or the next strip's
+    // first band, requested while this band is processed).  Row offsets are 32-bit adds from the first row's offset, clamped to
+    // the band's last row; the piece offset is clamped to the level's last 16 bytes of a row (pieces beyond the level's width hold
+    // columns no cell reaches).
     const int rq = (lane * 5) >> 6, dq = lane - 13 * rq;   // lane / 13, lane % 13  (lanes 52..63: rq = 4, idle)
-    // (twelve named registers, not an array: the array form of this window ends up in scratch memory)
-#define FS_FOR_LOADS(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
-    static_assert(FS_LOADS == 12, "FS_FOR_LOADS lists the loads");
+    // (named registers, not an array: the array form of this window ends up in scratch memory)
+#define FS_FOR_LOADS(M) M(0) M(1) M(2) M(3) M(4) M(5)
+    static_assert(FS_LOADS == 6, "FS_FOR_LOADS lists the loads");
 #define FS_DECL(k) uint4 tv##k;
     FS_FOR_LOADS(FS_DECL)
 #undef FS_DECL
     uint32_t tcf = 0;
-    OrbxFastGroup grp_n = strips[g0];
-    OrbxCell c0_n = cells[grp_n.cell0];
     const uint8_t *fbase = pyr + (long long)f * g.pyr_bytes;
-#define FS_ROW_OFFSETS(CELL, LV, o, olast, vpitch4)                                                                        \
+    // bands of a strip whose cells are `ch` rows tall: nb bands of bh interior rows (the last one takes what is left)
+#define FS_BANDS(ch, nb, bh) const int nb = max(1, ((ch) - 6 + bhmax - 1) / bhmax), bh = ((ch) - 6 + nb - 1) / nb;
+    // first tile row (cell coordinates) and number of tile rows of band b
+#define FS_BAND_ROWS(ch, bh, b, trow0, tnrows) const int trow0 = (b) * (bh), tnrows = min((ch), trow0 + (bh) + 6) - trow0;
+#define FS_ROW_OFFSETS(CELL, LV, trow0, tnrows, o, olast, vpitch4)                                                         \
         uint32_t vpitch4 = (uint32_t)(4 * LV.pitch);                                                                      \
         asm("" : "+v"(vpitch4));   /* in a VGPR: a VOP2 add with an SGPR source issues at the slow rate */                  \
         const uint32_t xoff_ = (uint32_t)min((CELL.x0 & ~3) + 16 * dq, LV.pitch - 16);                                    \
-        const uint32_t olast = (uint32_t)__mul24((int)CELL.y0 + (int)CELL.ch - 1, LV.pitch) + xoff_;                      \
-        uint32_t o = (uint32_t)__mul24((int)CELL.y0 + min(rq, 3), LV.pitch) + xoff_;
+        const uint32_t olast = (uint32_t)__mul24((int)CELL.y0 + (trow0) + (tnrows) - 1, LV.pitch) + xoff_;                \
+        uint32_t o = (uint32_t)__mul24((int)CELL.y0 + (trow0) + min(rq, 3), LV.pitch) + xoff_;
 #define FS_LOAD1(k) tv##k = *(const uint4 *)(srcn + min(o, olast)); o += vpitch4;
+    // the item the registers hold: band pf_b of strip pf_s (of this wave's strips)
+    int pf_s = 0, pf_b = 0;
+    OrbxFastGroup pf_grp = strips[g0];
+    OrbxCell pf_c0 = cells[pf_grp.cell0];
 #define FS_PREFETCH()                                                                                                     \
     {                                                                                                                     \
-        const DLevel &Ln = g.lv[c0_n.level];                                                                             \
+        const DLevel &Ln = g.lv[pf_c0.level];                                                                            \
         const uint8_t *srcn = fbase + Ln.off;                                                                             \
-        FS_ROW_OFFSETS(c0_n, Ln, o, olast, vpitch4)                                                                       \
+        FS_BANDS(pf_c0.ch, nbn, bhn)                                                                                      \
+        FS_BAND_ROWS(pf_c0.ch, bhn, pf_b, trow0n, tnrowsn)                                                                \
+        FS_ROW_OFFSETS(pf_c0, Ln, trow0n, tnrowsn, o, olast, vpitch4)                                                     \
         FS_FOR_LOADS(FS_LOAD1)                                                                                            \
-        tcf = ((const uint32_t *)strip_cellof)[(size_t)(g0 + gi_n) * (ORBX_STRIP_TILE_COLS / 4) + min(lane, ORBX_STRIP_TILE_COLS / 4 - 1)]; \
+        tcf = ((const uint32_t *)strip_cellof)[(size_t)(g0 + pf_s) * (ORBX_STRIP_TILE_COLS / 4) + min(lane, ORBX_STRIP_TILE_COLS / 4 - 1)]; \
     }
-    int gi_n = 0;
+    // band (c0, b) straight from memory (threshold retry, sub-band after a corner-list overflow): all loads in flight, then the stores
+#define FS_RESTAGE(c0, L, trow0, tnrows)                                                                                  \
+    {                                                                                                                     \
+        const uint8_t *src = fbase + L.off;                                                                               \
+        FS_ROW_OFFSETS(c0, L, trow0, tnrows, o, olast, vpitch4)                                                           \
+        uint4 t[FS_LOADS];                                                                                                \
+        _Pragma("unroll") for (int k = 0; k < FS_LOADS; ++k) { t[k] = *(const uint4 *)(src + min(o, olast)); o += vpitch4; } \
+        _Pragma("unroll") for (int k = 0; k < FS_LOADS; ++k)                                                              \
+            if (rq < 4 && 4 * k + rq < (tnrows)) *(uint4 *)(s_tile + (4 * k + rq) * FS_TP + 16 * dq) = t[k];              \
+        orbx_wave_sync();                                                                                                 \
+    }
     FS_PREFETCH()
   for (int gi = 0; gi < ng; ++gi) {
-    const OrbxFastGroup grp = grp_n;
-    const OrbxCell c0 = c0_n;
+    // (pf_grp / pf_c0 describe this strip: they were loaded with the request for its first band, a band or a strip ago)
+    const OrbxFastGroup grp = pf_grp;
+    const OrbxCell c0 = pf_c0;
     const DLevel &L = g.lv[c0.level];
-    const int th_rows = c0.ch;
     const int ncell = grp.ncell;
-    // ---- stage the tile: prefetched registers -> LDS; per-cell tables
-    {
-        uint8_t *trow = s_tile + rq * FS_TP + 16 * dq;
-#define FS_STORE1(k) if (rq < 4 && 4 * k + rq < th_rows) *(uint4 *)(trow + 4 * k * FS_TP) = tv##k;
-        FS_FOR_LOADS(FS_STORE1)
-#undef FS_STORE1
-        if (th_rows > 4 * FS_LOADS) {   // cells taller than the register window (tiny pyramid levels only)
-            const uint8_t *src = fbase + L.off;
-            FS_ROW_OFFSETS(c0, L, o, olast, vpitch4)
-            o += (uint32_t)FS_LOADS * vpitch4;
-            for (int r = 4 * FS_LOADS + rq; r < th_rows; r += 4) {
-                if (rq < 4) *(uint4 *)(s_tile + r * FS_TP + 16 * dq) = *(const uint4 *)(src + min(o, olast));
-                o += vpitch4;
-            }
-        }
-        if (lane < ORBX_STRIP_TILE_COLS / 4) ((uint32_t *)s_cellof)[lane] = tcf;
-        if (lane < ncell) {
-            const OrbxCell cj = cells[grp.cell0 + lane];
-            s_ctab[lane] = make_uint2((uint32_t)(uint16_t)cj.offx | ((uint32_t)(cj.x0 - c0.x0) << 16), (uint32_t)cj.idx_in_level);
-            s_ccapv[lane] = cj.slot_cap;
-        }
-    }
-    if (gi + 1 < ng) {
-        gi_n = gi + 1;
-        grp_n = strips[g0 + gi_n];
-        c0_n = cells[grp_n.cell0];
-        FS_PREFETCH()
-    }
+    const int yend = c0.ch - 3;
+    FS_BANDS(c0.ch, nb, bh)
     FsCtx cx;
     cx.tile = s_tile + (c0.x0 & 3);
     cx.tile0 = s_tile;
@@ -1127,149 +1117,218 @@ __global__ __launch_bounds__(64, FS_WPS) void k_fast_strip(DGeom g, const OrbxCe
     go.cursor = cand_cursor + f * g.nlevels + c0.level;
     go.out_cap = L.cand_cap;
     go.offy = c0.offy;
-    orbx_wave_sync();
-    if (dbg_stop == 1) continue;
-    const bool two_th = g.min_th != g.ini_th;
-    const int yend = th_rows - 3;
-    const uint8_t *pc = cx.tile + 3 * lane;                  // this lane's three columns, row 0
+    const bool two_th = g.min_th != g.ini_th && dbg_stop != 5;   // (5: timing build, no threshold retry)
+    const uint8_t *pc = cx.tile + 3 * lane;                  // this lane's three columns, tile row 0
     unsigned act_ini = (1u << ncell) - 1u, act_min = 0u;     // cells still to be detected at iniThFAST / minThFAST
-    bool tile_ok = true, single = false;
-    while ((act_ini | act_min) != 0u) {
-        const unsigned pool = act_ini != 0u ? act_ini : act_min;
-        const int th = act_ini != 0u ? g.ini_th : g.min_th;
-        const unsigned act = single ? (pool & (0u - pool)) : pool;   // after a corner-list overflow: one cell per pass
-        if (!tile_ok) {   // the last pass's NMS turned the tile into its score map: stage it again (L2 hit)
-            const uint8_t *src = fbase + L.off;
-            FS_ROW_OFFSETS(c0, L, o, olast, vpitch4)
-            for (int r = rq; r < th_rows; r += 4) {
-                if (rq < 4) *(uint4 *)(s_tile + r * FS_TP + 16 * dq) = *(const uint4 *)(src + min(o, olast));
-                o += vpitch4;
-            }
-            tile_ok = true;
-            orbx_wave_sync();
-        }
-        // per-lane threshold constants: a field whose column is outside the strip or in a cell that is not part of this pass
-        // carries th = 255 (no 8-bit difference exceeds it): the pre-test needs no lane or column mask
-        uint32_t KH = 0, KL = 0;
+    int nsk[ORBX_STRIP_MAXCELLS];                            // survivors per cell (capped mode)
 #pragma unroll
-        for (int fq = 0; fq < 3; ++fq) {
-            const int kc = s_cellof[3 * lane + fq] & 7;
-            const int thf = ((act >> kc) & 1u) ? th : 255;
-            KH += (uint32_t)(thf + 1 - 512) << (10 * fq);
-            KL += (uint32_t)(511 - thf) << (10 * fq);
-        }
-        int nctot = 0;
-        bool overflow = false;
-        int y = 3;
-        const uint32_t ent0 = (uint32_t)(uintptr_t)(fs_lds_u32 *)s_ent;
-        const uint32_t dummy = ent0 + 4u * (uint32_t)ecap + 4u * (uint32_t)lane;
-        while (y < yend && !overflow) {
-            // ---- compass pre-test, one row per step, three pixels per lane (see the header)
-            const uint8_t *pr = pc + y * FS_TP;
+    for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) nsk[k] = 0;
+    while ((act_ini | act_min) != 0u) {
+        const unsigned act = act_ini != 0u ? act_ini : act_min;
+        const int th = act_ini != 0u ? g.ini_th : g.min_th;
+        uint32_t KH = 0, KL = 0;   // per-lane threshold constants (set once the strip's column table is in LDS)
+        int ncarry = 0;            // corners of the two tile rows above the current rows, kept for the next NMS
+        for (int b = 0; b < nb; ++b) {
+            FS_BAND_ROWS(c0.ch, bh, b, trow0, tnrows)   // tile row r <-> cell row trow0 + r
+            const int ba = 3 + b * bh, bb = min(yend, ba + bh);   // interior rows of the band (cell coordinates)
+            int span = bb - ba;
+            for (int wa = ba; wa < bb;) {
+                const int wb = min(bb, wa + span);
+                // ---- stage the band's tile
+                // (the registers hold band pf_b of strip pf_s: this band on the strip's first pass -- every band's first staging
+                // requests the item after it; a threshold-retry pass and the second half of a split band come from memory)
+                if (pf_s == gi && pf_b == b && wa == ba) {
+                    uint8_t *trow = s_tile + rq * FS_TP + 16 * dq;
+#define FS_STORE1(k) if (rq < 4 && 4 * k + rq < tnrows) *(uint4 *)(trow + 4 * k * FS_TP) = tv##k;
+                    FS_FOR_LOADS(FS_STORE1)
+#undef FS_STORE1
+                    if (b == 0) {   // per-strip tables
+                        if (lane < ORBX_STRIP_TILE_COLS / 4) ((uint32_t *)s_cellof)[lane] = tcf;
+                        if (lane < ncell) {
+                            const OrbxCell cj = cells[grp.cell0 + lane];
+                            s_ctab[lane] = make_uint2((uint32_t)(uint16_t)cj.offx | ((uint32_t)(cj.x0 - c0.x0) << 16), (uint32_t)cj.idx_in_level);
+                            s_ccapv[lane] = cj.slot_cap;
+                        }
+                        if (lane < ORBX_STRIP_MAXCELLS) s_hit[lane] = 0;
+                    }
+                    // request the next item: the next band of this strip, or the first band of the wave's next strip
+                    if (b + 1 < nb) { pf_b = b + 1; FS_PREFETCH() }
+                    else if (gi + 1 < ng) { pf_s = gi + 1; pf_b = 0; pf_grp = strips[g0 + pf_s]; pf_c0 = cells[pf_grp.cell0]; FS_PREFETCH() }
+                    orbx_wave_sync();
+                } else {
+                    FS_RESTAGE(c0, L, trow0, tnrows)
+                }
+                if (dbg_stop == 1) { wa = wb; continue; }
+                if (b == 0 && wa == ba) {
+                    // a field whose column is outside the strip or in a cell that is not part of this pass carries th = 255 (no
+                    // 8-bit difference exceeds it): the pre-test needs no lane or column mask
+                    KH = 0; KL = 0;
+#pragma unroll
+                    for (int fq = 0; fq < 3; ++fq) {
+                        const int kc = s_cellof[3 * lane + fq] & 7;
+                        const int thf = ((act >> kc) & 1u) ? th : 255;
+                        KH += (uint32_t)(thf + 1 - 512) << (10 * fq);
+                        KL += (uint32_t)(511 - thf) << (10 * fq);
+                    }
+                }
+                // ---- detect the corners of cell rows [wa, wb): tile rows [wa - trow0, wb - trow0)
+                int nctot = ncarry;
+                bool overflow = false;
+                int y = wa - trow0;
+                const int ye = wb - trow0;
+                const uint32_t ent0 = (uint32_t)(uintptr_t)(fs_lds_u32 *)s_ent;
+                const uint32_t dummy = ent0 + 4u * (uint32_t)ecap + 4u * (uint32_t)lane;
+                bool slow = false;   // a 7-row chunk overran the entry list: single rows for the rest of these rows
+                while (y < ye && !overflow) {
+                    // ---- compass pre-test, one row per step, three pixels per lane (see the header)
+                    const uint8_t *pr = pc + y * FS_TP;
 #define FS_PACK(p) ((uint32_t)(p)[0] | ((uint32_t)(p)[1] << 10) | ((uint32_t)(p)[2] << 20))
-            uint32_t w0 = FS_PACK(pr - 3 * FS_TP), w1 = FS_PACK(pr - 2 * FS_TP), w2 = FS_PACK(pr - FS_TP), w3 = FS_PACK(pr),
-                     w4 = FS_PACK(pr + FS_TP), w5 = FS_PACK(pr + 2 * FS_TP), w6;
-            uint32_t nb = ent0;
-            uint32_t code = (uint32_t)((y << 10) | lane);
-            // software-pipelined: the three LDS bytes of row y+4 are requested before row y is evaluated; the row after the
-            // last one is read but never used (it lies inside the LDS allocation)
-            uint32_t nx0 = pr[3 * FS_TP], nx1 = pr[3 * FS_TP + 1], nx2 = pr[3 * FS_TP + 2];
+                    uint32_t w0 = FS_PACK(pr - 3 * FS_TP), w1 = FS_PACK(pr - 2 * FS_TP), w2 = FS_PACK(pr - FS_TP), w3 = FS_PACK(pr),
+                             w4 = FS_PACK(pr + FS_TP), w5 = FS_PACK(pr + 2 * FS_TP), w6;
+                    uint32_t nb_ = ent0;
+                    uint32_t code = (uint32_t)((y << 10) | lane);
+                    // software-pipelined: the three LDS bytes of row y+4 are requested before row y is evaluated; the row after
+                    // the last one is read but never used (it lies inside the LDS allocation)
+                    uint32_t nx0 = pr[3 * FS_TP], nx1 = pr[3 * FS_TP + 1], nx2 = pr[3 * FS_TP + 2];
 #define FS_STEP(R8, C, R0)                                                                                              \
-            {                                                                                                           \
-                R0 = nx0 | (nx1 << 10) | (nx2 << 20);                                                                   \
-                pr += FS_TP;                                                                                            \
-                nx0 = pr[3 * FS_TP]; nx1 = pr[3 * FS_TP + 1]; nx2 = pr[3 * FS_TP + 2];                                  \
-                asm("" : "+v"(nx0), "+v"(nx1), "+v"(nx2));                                                              \
-                const uint32_t aH = C + KH, aL = C + KL;                                                                \
-                const uint32_t vc = FS_ONES - C, aV = vc + KH;   /* the row complemented: darker = brighter there */     \
-                const uint32_t cr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xf, 0xf, true);            \
-                const uint32_t cl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xf, 0xf, true);            \
-                const uint32_t vr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vc, 0x130, 0xf, 0xf, true);           \
-                const uint32_t vl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vc, 0x138, 0xf, 0xf, true);           \
-                const uint32_t bb = ((R0 - aH) | (R8 - aH)) & ((cr - aH) | (cl - aH));                                  \
-                const uint32_t dd = ((aL - R0) | (aL - R8)) & ((vr - aV) | (vl - aV));                                  \
-                const uint32_t cc = (bb | dd) & FS_FMASK;                                                               \
-                const bool cnd = cc != 0u;                                                                              \
-                const unsigned long long m = orbx_ballot(cnd);                                                          \
-                *(fs_lds_u32 *)(uintptr_t)(cnd ? nb + 4u * (uint32_t)orbx_wave_rank(m) : dummy) = cc | code;            \
-                nb += 4u * (uint32_t)__popcll(m);                                                                       \
-                code += 0x400u;                                                                                         \
-            }
-            while (y + 7 <= yend && nb + 7u * 256u <= ent0 + 4u * (uint32_t)ecap) {
-                FS_STEP(w0, w3, w6)
-                FS_STEP(w1, w4, w0)
-                FS_STEP(w2, w5, w1)
-                FS_STEP(w3, w6, w2)
-                FS_STEP(w4, w0, w3)
-                FS_STEP(w5, w1, w4)
-                FS_STEP(w6, w2, w5)
-                y += 7;
-            }
-            while (y < yend && nb + 256u <= ent0 + 4u * (uint32_t)ecap) {
-                FS_STEP(w0, w3, w6)
-                w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6;
-                ++y;
-            }
+                    {                                                                                                   \
+                        R0 = nx0 | (nx1 << 10) | (nx2 << 20);                                                           \
+                        pr += FS_TP;                                                                                    \
+                        nx0 = pr[3 * FS_TP]; nx1 = pr[3 * FS_TP + 1]; nx2 = pr[3 * FS_TP + 2];                          \
+                        asm("" : "+v"(nx0), "+v"(nx1), "+v"(nx2));                                                      \
+                        const uint32_t aH = C + KH, aL = C + KL;                                                        \
+                        const uint32_t vc = FS_ONES - C, aV = vc + KH;   /* the row complemented: darker = brighter there */ \
+                        const uint32_t cr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xf, 0xf, true);    \
+                        const uint32_t cl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xf, 0xf, true);    \
+                        const uint32_t vr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vc, 0x130, 0xf, 0xf, true);   \
+                        const uint32_t vl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vc, 0x138, 0xf, 0xf, true);   \
+                        const uint32_t bb_ = ((R0 - aH) | (R8 - aH)) & ((cr - aH) | (cl - aH));                         \
+                        const uint32_t dd_ = ((aL - R0) | (aL - R8)) & ((vr - aV) | (vl - aV));                         \
+                        const uint32_t cc = (bb_ | dd_) & FS_FMASK;                                                     \
+                        const bool cnd = cc != 0u;                                                                      \
+                        const unsigned long long m = orbx_ballot(cnd);                                                  \
+                        *(fs_lds_u32 *)(uintptr_t)(cnd ? min(nb_ + 4u * (uint32_t)orbx_wave_rank(m), dummy) : dummy) = cc | code; \
+                        nb_ += 4u * (uint32_t)__popcll(m);                                                              \
+                        code += 0x400u;                                                                                 \
+                    }
+                    // Chunks of 7 rows are walked OPTIMISTICALLY: a row can add up to 62 entries but adds about 12, and reserving
+                    // the worst case for seven rows would double the list.  A store beyond the list lands in the lane's dummy
+                    // slot (the address is clamped: dummy = list end + lane); if the cursor shows that happened, the chunk's
+                    // entries are dropped, what was there before is flushed and the rows are walked again one at a time.
+                    const uint32_t ent_end = ent0 + 4u * (uint32_t)ecap;
+                    bool dropped = false;
+                    while (y + 7 <= ye && !slow && nb_ + 256u <= ent_end) {
+                        const uint32_t nb_save = nb_;
+                        FS_STEP(w0, w3, w6)
+                        FS_STEP(w1, w4, w0)
+                        FS_STEP(w2, w5, w1)
+                        FS_STEP(w3, w6, w2)
+                        FS_STEP(w4, w0, w3)
+                        FS_STEP(w5, w1, w4)
+                        FS_STEP(w6, w2, w5)
+                        if (nb_ > ent_end) { nb_ = nb_save; slow = true; dropped = true; break; }
+                        y += 7;
+                    }
+                    if (!dropped)   // (after a dropped chunk: flush what was there, prime the window again, then single rows)
+                    while (y < ye && nb_ + 256u <= ent_end && (slow || y + 7 > ye)) {
+                        FS_STEP(w0, w3, w6)
+                        w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6;
+                        ++y;
+                    }
 #undef FS_STEP
 #undef FS_PACK
-            const int ne = (int)((nb - ent0) >> 2);
-            orbx_wave_sync();
-            if (dbg_stop == 2) { if (ne == 12345) cand_cursor[0] = ne; continue; }
-            // ---- entries -> pixel codes (order kept: row-major over the strip), ring test + score in full rounds
-            int nl = 0;
-            for (int e0 = 0; e0 < ne && !overflow; e0 += 64) {
-                if (nl + 192 > lcap) {
-                    overflow = !fs_ring_and_score(cx, nl, th, nctot, dbg_stop);
-                    nl = 0;
-                    if (overflow) break;
+                    const int ne = (int)((nb_ - ent0) >> 2);
+                    orbx_wave_sync();
+                    if (dbg_stop == 2) { if (ne == 12345) cand_cursor[0] = ne; continue; }
+                    // ---- entries -> pixel codes (order kept: row-major over the strip), ring test + score in full rounds
+                    int nl = 0;
+                    for (int e0 = 0; e0 < ne && !overflow; e0 += 64) {
+                        const int e = e0 + lane;
+                        const uint32_t en = e < ne ? s_ent[e] : 0u;
+                        const int f0 = (en >> 9) & 1, f1 = (en >> 19) & 1, f2 = (en >> 29) & 1;
+                        const int cnt = f0 + f1 + f2;
+                        const int incl = orbx_wave_scan(cnt);
+                        const int tot = __builtin_amdgcn_readlane(incl, 63);
+                        if (nl + tot > lcap) {   // the list cannot take this chunk's pixels (<= 192): ring test + score what it holds
+                            overflow = !fs_ring_and_score(cx, nl, th, nctot, dbg_stop);
+                            nl = 0;
+                            if (overflow) break;
+                        }
+                        const uint32_t cb = (((en >> 10) & 0x7fu) << 8) + 3u * (en & 63u) - 3u;
+                        uint16_t *lp = s_list + nl + incl - cnt;
+                        if (f0) { *lp = (uint16_t)cb; ++lp; }
+                        if (f1) { *lp = (uint16_t)(cb + 1u); ++lp; }
+                        if (f2) { *lp = (uint16_t)(cb + 2u); }
+                        nl += tot;
+                    }
+                    orbx_wave_sync();
+                    if (!overflow && nl > 0) overflow = !fs_ring_and_score(cx, nl, th, nctot, dbg_stop);
                 }
-                const int e = e0 + lane;
-                const uint32_t en = e < ne ? s_ent[e] : 0u;
-                const int f0 = (en >> 9) & 1, f1 = (en >> 19) & 1, f2 = (en >> 29) & 1;
-                const int cnt = f0 + f1 + f2;
-                const int incl = orbx_wave_scan(cnt);
-                const int tot = __builtin_amdgcn_readlane(incl, 63);
-                const uint32_t cb = (((en >> 10) & 0x7fu) << 8) + 3u * (en & 63u) - 3u;
-                uint16_t *lp = s_list + nl + incl - cnt;
-                if (f0) { *lp = (uint16_t)cb; ++lp; }
-                if (f1) { *lp = (uint16_t)(cb + 1u); ++lp; }
-                if (f2) { *lp = (uint16_t)(cb + 2u); }
-                nl += tot;
+                if (overflow) {
+                    // the corners of these rows do not fit the corner list: take half the rows (the tile is intact: NMS has
+                    // not run).  One row with the two rows carried above it always fits (host: ccap >= 3 x strip width).
+                    if (wb - wa <= 1) { if (lane == 0) atomicMax(&status[f], (int)ORBX_CAPACITY); wa = wb; ncarry = 0; }
+                    else span = (wb - wa + 1) >> 1;
+                    continue;
+                }
+                if (dbg_stop >= 2 && dbg_stop != 5) {
+                    if (lane < ORBX_STRIP_MAXCELLS) s_hit[lane] = 1;
+                    wa = wb; ncarry = 0;
+                    orbx_wave_sync();
+                    continue;
+                }
+                // ---- NMS of the rows whose neighbours are all known: [wa - 1, wb - 1) ([.., wb) on the strip's last rows)
+                const bool last = wb == yend;
+                fs_nms(cx, go, nctot, tnrows, wa - 1 - trow0, (last ? wb : wb - 1) - trow0, trow0, capped != 0, nsk);
+                // ---- corners of the last two rows go on to the next NMS, re-based to the tile they will be scattered into
+                ncarry = 0;
+                if (!last) {
+                    const int klo = wb - 2 - trow0;
+                    const int rebase = (wb == bb) ? bh : 0;   // the next band's tile starts bh rows further down
+                    for (int e0 = 0; e0 < nctot; e0 += 64) {
+                        const int e = e0 + lane;
+                        const uint16_t code = e < nctot ? s_corn[e] : (uint16_t)0;
+                        const uint8_t sc = e < nctot ? s_cscore[e] : (uint8_t)0;
+                        const bool kp = e < nctot && (code >> 8) >= klo;
+                        const unsigned long long m = orbx_ballot(kp);
+                        if (kp) {   // index <= e: this round's entries are already in registers
+                            const int d = ncarry + orbx_wave_rank(m);
+                            s_corn[d] = (uint16_t)(code - (rebase << 8));
+                            s_cscore[d] = sc;
+                        }
+                        ncarry += __popcll(m);
+                    }
+                    orbx_wave_sync();
+                }
+                wa = wb;
             }
-            orbx_wave_sync();
-            if (!overflow && nl > 0) overflow = !fs_ring_and_score(cx, nl, th, nctot, dbg_stop);
-        }
-        if (overflow) {
-            if ((act & (act - 1u)) == 0u) {   // a single cell's corners always fit (host: ccap >= largest cell interior)
-                if (lane == 0) atomicMax(&status[f], (int)ORBX_CAPACITY);
-                act_ini &= ~act; act_min &= ~act;
-            }
-            single = true;
-            continue;   // the tile is intact: NMS has not run
-        }
-        if (lane < ORBX_STRIP_MAXCELLS) s_hit[lane] = 0;
-        if (dbg_stop >= 2) {
-            if (lane < ORBX_STRIP_MAXCELLS) s_hit[lane] = 1;
-            orbx_wave_sync();
-        } else {
-            fs_nms(cx, go, nctot, th_rows, capped != 0, ncell, &status[f]);
-            tile_ok = false;
         }
         unsigned hits = 0u;
 #pragma unroll
         for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) hits |= (k < ncell && s_hit[k] != 0) ? (1u << k) : 0u;
         hits = (unsigned)__builtin_amdgcn_readfirstlane((int)hits);   // (wave-uniform by construction: keeps the pass loop scalar)
-        // vKeysCell.empty() -> that cell alone repeats with minThFAST (:1519-1527)
-        if (act_ini != 0u) { act_ini &= ~act; if (two_th) act_min |= act & ~hits; }
-        else act_min &= ~act;
         orbx_wave_sync();
+        if (lane < ORBX_STRIP_MAXCELLS) s_hit[lane] = 0;
+        // vKeysCell.empty() -> that cell alone repeats with minThFAST (:1519-1527)
+        if (act_ini != 0u) { act_ini = 0u; if (two_th) act_min = act & ~hits; }
+        else act_min = 0u;
+        orbx_wave_sync();
+    }
+    if (capped) {   // more survivors than a cell may report: reported, not silent
+        bool over = false;
+#pragma unroll
+        for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) over = over || (k < ncell && nsk[k] > s_ccapv[k]);
+        if (over && lane == 0) atomicMax(&status[f], (int)ORBX_CAPACITY);
     }
     orbx_wave_sync();   // the next strip overwrites tile / lists / tables
   }
 #undef FS_PREFETCH
+#undef FS_RESTAGE
 #undef FS_LOAD1
 #undef FS_FOR_LOADS
 #undef FS_ROW_OFFSETS
+#undef FS_BANDS
+#undef FS_BAND_ROWS
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2847,7 +2906,10 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
     if (ngroups <= 0) return;
     lcap = (max(lcap, 64) + 1) & ~1;
     max_ch = (max_ch + 3) & ~3;   // tile and score map sizes multiples of 16 bytes
-    const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256;
+#ifndef FR_PAD
+#define FR_PAD 0
+#endif
+    const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256 + FR_PAD;
     // groups per wave: FR_GPW when the launch has waves to spare (the second group's tile is prefetched while the first
     // is processed); one per wave for small batches, where the serial length of a wave is what the caller waits for
     const int gpw = (long long)B * ngroups >= 16384 ? FR_GPW : 1;
@@ -2856,19 +2918,20 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
 }
 void orbx_launch_fast_strip(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *strips,
                             const uint8_t *strip_cellof, int nstrips, const uint8_t *pyr, uint2 *cand, int *cand_cursor,
-                            int *status, int max_ch, int ecap, int lcap, int ccap, int capped, int dbg_stop) {
+                            int *status, int bhmax, int ecap, int lcap, int ccap, int capped, int dbg_stop) {
     if (nstrips <= 0) return;
+    bhmax = min(max(bhmax, 1), 4 * FS_LOADS - 6);   // a band's tile (band + 6 ring rows) must fit the register window
     ecap = (max(ecap, 64) + 1) & ~1;
     lcap = (max(lcap, 192) + 3) & ~3;
-    ccap = (max(ccap, 64) + 7) & ~7;
-    max_ch = (max_ch + 3) & ~3;
-    const size_t smem = (size_t)max_ch * FS_TP + (size_t)4 * (ecap + 64) + (size_t)2 * lcap + (size_t)3 * ccap +
+    ccap = (max(ccap, 3 * ORBX_STRIP_TILE_COLS) + 7) & ~7;   // one row + the two rows carried above it always fit
+    const int rows = (bhmax + 6 + 3) & ~3;
+    const size_t smem = (size_t)rows * FS_TP + (size_t)4 * (ecap + 64) + (size_t)2 * lcap + (size_t)3 * ccap +
                         ORBX_STRIP_TILE_COLS + 8 * sizeof(uint2) + 16 * sizeof(int);
-    // strips per wave: 2 when the launch has waves to spare (the second strip's tile is prefetched while the first is
-    // processed); one per wave for small batches, where the serial length of a wave is what the caller waits for
+    // strips per wave: 2 when the launch has waves to spare; one per wave for small batches, where the serial length of a
+    // wave is what the caller waits for (the bands of one strip already overlap their loads with the work)
     const int spw = (long long)B * nstrips >= 8192 ? 2 : 1;
     hipLaunchKernelGGL(k_fast_strip, dim3(B, (nstrips + spw - 1) / spw), dim3(64), smem, s, g, cells, strips, strip_cellof, pyr,
-                       cand, cand_cursor, status, max_ch, ecap, lcap, ccap, nstrips, spw, capped, dbg_stop);
+                       cand, cand_cursor, status, rows, bhmax, ecap, lcap, ccap, nstrips, spw, capped, dbg_stop);
 }
 void orbx_launch_undistort(hipStream_t s, int B, int max_n, int cap, const double *K4, const double *k14, int identity,
                            const orbx_keypoint *kps, const int *counts, orbx_keypoint *out) {
