@@ -49,10 +49,6 @@ struct orbx_handle {
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     OrbxCell *d_cells = nullptr;
     OrbxFastGroup *d_groups = nullptr;
-    OrbxFastGroup *d_strips = nullptr;      // k_fast_strip work items
-    uint8_t *d_cellof = nullptr;            // their column -> cell tables
-    bool fast_rows = false;                 // ORBX_FAST_IMPL=rows: round-2 kernel (A/B runs during development)
-    int fast_ecap = 384, fast_lcap2 = 512, fast_ccap = 576, fast_bh = 16;   // LDS list capacities / band height of k_fast_strip
     bool resize_legacy = false;   // ORBX_RESIZE_IMPL=legacy: k_pyr_resize for every level (A/B runs)
     int fast_stop = 0;      // ORBX_FAST_STOP: only read in -DORBX_TIMING_KNOBS builds
     int fast_lcap = 640;    // LDS work-list entries of k_fast_rows (ORBX_FAST_LCAP; tests shrink it to force the flush paths)
@@ -178,8 +174,6 @@ static orbx_status pin_reserve(orbx_handle *h, size_t bytes);   // page-locked h
 // ---------------------------------------------------------------- workspace
 static void free_geometry_buffers(orbx_handle *h) {
     hipFree(h->d_groups); h->d_groups = nullptr;
-    hipFree(h->d_strips); h->d_strips = nullptr;
-    hipFree(h->d_cellof); h->d_cellof = nullptr;
     hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cells); hipFree(h->d_taps);
     hipFree(h->d_dense); h->d_dense = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_lvl_count); hipFree(h->d_status); hipFree(h->d_lvl_kp);
@@ -271,14 +265,6 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     if (const char *e = getenv("ORBX_FAST_STOP")) h->fast_stop = atoi(e);
 #endif
     if (const char *e = getenv("ORBX_FAST_LCAP")) h->fast_lcap = std::max(64, atoi(e));
-    if (const char *e = getenv("ORBX_FAST_IMPL")) h->fast_rows = strcmp(e, "rows") == 0;
-    // k_fast_strip: ORBX_FAST_LCAP shrinks the three LDS lists to force the flush / band-splitting paths (tests; the launcher keeps
-    // the corner list >= three strip rows), ORBX_FAST_BH sets the band height (A/B runs)
-    h->fast_ecap = 384; h->fast_lcap2 = 512; h->fast_ccap = 576; h->fast_bh = 16;
-    if (const char *e = getenv("ORBX_FAST_LCAP")) { const int v = std::max(64, atoi(e)); h->fast_ecap = v; h->fast_lcap2 = v; h->fast_ccap = v; }
-    if (const char *e = getenv("ORBX_FAST_BH")) h->fast_bh = std::max(1, atoi(e));
-    if (const char *e = getenv("ORBX_FAST_ECAP")) h->fast_ecap = std::max(64, atoi(e));
-    if (const char *e = getenv("ORBX_FAST_CCAP")) h->fast_ccap = std::max(64, atoi(e));
     const OrbxGeom &hg = h->geom;
     hipStream_t s = h->stream;
     // Optional fork of the batched launch sequence (run_chunk): ORBX_FORK_LEVEL = l > 0 resizes levels >= l and runs their
@@ -289,10 +275,9 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     if (const char *e = getenv("ORBX_FORK_LEVEL")) h->fork_level = std::min(std::max(atoi(e), 0), NL - 1);
     h->fork_group = 0;
     if (h->fork_level > 0) {
-        const std::vector<OrbxFastGroup> &wg = h->fast_rows ? hg.fast_groups : hg.fast_strips;
-        while (h->fork_group < (int)wg.size() && hg.cells[(size_t)wg[(size_t)h->fork_group].cell0].level < h->fork_level)
+        while (h->fork_group < (int)hg.fast_groups.size() && hg.cells[(size_t)hg.fast_groups[(size_t)h->fork_group].cell0].level < h->fork_level)
             ++h->fork_group;
-        if (h->fork_group == 0 || h->fork_group >= (int)wg.size()) h->fork_level = 0;
+        if (h->fork_group == 0 || h->fork_group >= (int)hg.fast_groups.size()) h->fork_level = 0;
     }
     auto setup = [&]() -> hipError_t {
         hipError_t e;
@@ -308,15 +293,10 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
         ORBX_TRY(hipMalloc(&h->d_lvl_kp, (size_t)B * hg.kp_total * sizeof(uint32_t)));
         ORBX_TRY(hipMalloc(&h->d_lvl_angle, (size_t)B * hg.kp_total * sizeof(float)));
         ORBX_TRY(hipMalloc(&h->d_groups, std::max<size_t>(1, hg.fast_groups.size()) * sizeof(OrbxFastGroup)));
-        ORBX_TRY(hipMalloc(&h->d_strips, std::max<size_t>(1, hg.fast_strips.size()) * sizeof(OrbxFastGroup)));
-        ORBX_TRY(hipMalloc(&h->d_cellof, std::max<size_t>(1, hg.strip_cellof.size())));
         if (!hg.cells.empty()) {
             ORBX_TRY(hipMemcpyAsync(h->d_cells, hg.cells.data(), hg.cells.size() * sizeof(OrbxCell), hipMemcpyHostToDevice, s));
             ORBX_TRY(hipMemcpyAsync(h->d_groups, hg.fast_groups.data(), hg.fast_groups.size() * sizeof(OrbxFastGroup),
                                     hipMemcpyHostToDevice, s));
-            ORBX_TRY(hipMemcpyAsync(h->d_strips, hg.fast_strips.data(), hg.fast_strips.size() * sizeof(OrbxFastGroup),
-                                    hipMemcpyHostToDevice, s));
-            ORBX_TRY(hipMemcpyAsync(h->d_cellof, hg.strip_cellof.data(), hg.strip_cellof.size(), hipMemcpyHostToDevice, s));
         }
         if (!hg.taps.empty())
             ORBX_TRY(hipMemcpyAsync(h->d_taps, hg.taps.data(), hg.taps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice, s));
@@ -503,17 +483,7 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
     // Large batches fork after level fork_level - 1: the remaining (small) levels are resized on the high-priority side stream
     // -- seven dependent launches of which the last four have few waves and are pure latency -- followed by their FAST
     // groups, while the main stream runs the issue-bound FAST kernel of the large levels; joined before the quadtree.
-    const int ngroups = (int)(h->fast_rows ? h->geom.fast_groups.size() : h->geom.fast_strips.size());
-    const int capped = h->p.max_cand_per_cell > 0 ? 1 : 0;
-    auto launch_fast = [&](hipStream_t st, int first, int count) {
-        if (h->fast_rows)
-            orbx_launch_fast_rows(st, g, B, h->d_cells, h->d_groups + first, count, h->d_pyr, h->d_dense, h->d_cand_count, d_status,
-                                  h->max_ch, h->fast_lcap, h->fast_stop);
-        else
-            orbx_launch_fast_strip(st, g, B, h->d_cells, h->d_strips + first, h->d_cellof + (size_t)first * ORBX_STRIP_TILE_COLS, count,
-                                   h->d_pyr, h->d_dense, h->d_cand_count, d_status, h->fast_bh, h->fast_ecap, h->fast_lcap2,
-                                   h->fast_ccap, capped, h->fast_stop);
-    };
+    const int ngroups = (int)h->geom.fast_groups.size();
     const bool fork = h->fork_level > 0 && (long long)B * ngroups >= 16384;
     const int l_main_end = fork ? h->fork_level : NL;
     for (int l = 1; l < l_main_end; ++l) {
@@ -529,17 +499,20 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
             orbx_launch_pyr_resize(s2, g, B, l, h->d_taps, h->d_pyr, h->geom.lv[l].narrow_taps && !h->resize_legacy);
         }
         { ProfScope ps(h, ORBX_K_FAST, s2);
-          launch_fast(s2, h->fork_group, ngroups - h->fork_group); }
+          orbx_launch_fast_rows(s2, g, B, h->d_cells, h->d_groups + h->fork_group, ngroups - h->fork_group, h->d_pyr, h->d_dense,
+                                h->d_cand_count, d_status, h->max_ch, h->fast_lcap, h->fast_stop); }
         // (The quadtree of the small levels was tried on the side stream behind its FAST groups: it needs CU residency the
         // FAST kernel of the large levels does not give up -- 201 us for 1024 workgroups that take 57 us alone -- and delays the
         // join.  It runs after the join.)
         { ProfScope ps(h, ORBX_K_FAST);
-          launch_fast(s, 0, h->fork_group); }
+          orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, h->fork_group, h->d_pyr, h->d_dense,
+                                h->d_cand_count, d_status, h->max_ch, h->fast_lcap, h->fast_stop); }
         if (hipEventRecord(h->ev_join, s2) != hipSuccess || hipStreamWaitEvent(s, h->ev_join, 0) != hipSuccess)
             return fail(ORBX_HIP_ERROR, "join event");
     } else {
         ProfScope ps(h, ORBX_K_FAST);
-        launch_fast(s, 0, ngroups);
+        orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, ngroups, h->d_pyr, h->d_dense,
+                              h->d_cand_count, d_status, h->max_ch, h->fast_lcap, h->fast_stop);
     }
     { ProfScope ps(h, ORBX_K_QUADTREE);
       orbx_launch_quadtree(s, g, B, h->d_dense, h->d_cand_count, h->d_lvl_kp,

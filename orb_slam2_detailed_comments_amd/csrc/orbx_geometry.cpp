@@ -200,47 +200,6 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
         g.fast_groups.push_back(grp);
         i += (size_t)grp.ncell;
     }
-    // FAST strips (k_fast_strip): every maximal run of horizontally adjacent cells of a cell row is cut into the fewest
-    // strips of <= ORBX_STRIP_MAXCELLS cells / ORBX_STRIP_COLS interior columns, sizes as even as the cell count allows
-    g.max_cell_interior = 1;
-    for (size_t i = 0; i < g.cells.size();) {
-        size_t j = i + 1;
-        while (j < g.cells.size()) {
-            const OrbxCell &a = g.cells[j - 1], &b = g.cells[j];
-            if (!(b.level == a.level && b.y0 == a.y0 && b.ch == a.ch && b.x0 == a.x0 + a.cw - 6 && b.idx_in_level == a.idx_in_level + 1)) break;
-            ++j;
-        }
-        // greedy count of strips for the run [i, j), then an even split that still respects the column bound
-        size_t nstrips = 0;
-        for (size_t a = i; a < j;) {
-            int cols = 0; size_t b = a;
-            while (b < j && b - a < ORBX_STRIP_MAXCELLS && cols + (g.cells[b].cw - 6) <= ORBX_STRIP_COLS) { cols += g.cells[b].cw - 6; ++b; }
-            if (b == a) { *why = "FAST cell wider than a strip"; return ORBX_UNSUPPORTED; }
-            a = b; ++nstrips;
-        }
-        size_t a = i;
-        for (size_t k = 0; a < j; ++k) {
-            const size_t left = k < nstrips ? nstrips - k : 1;
-            const size_t want = (j - a + left - 1) / left;   // ceil(cells remaining / strips left); bounds below still hold
-            int cols = 0; size_t b = a;
-            while (b < j && b - a < want && b - a < ORBX_STRIP_MAXCELLS && cols + (g.cells[b].cw - 6) <= ORBX_STRIP_COLS) { cols += g.cells[b].cw - 6; ++b; }
-            OrbxFastGroup grp;
-            grp.cell0 = (int32_t)a; grp.ncell = (int32_t)(b - a);
-            g.fast_strips.push_back(grp);
-            const size_t base = g.strip_cellof.size();
-            g.strip_cellof.resize(base + ORBX_STRIP_TILE_COLS, 7);
-            int start = 3;
-            for (size_t c = a; c < b; ++c) {
-                const int iw = g.cells[c].cw - 6;
-                for (int x = 0; x < iw; ++x)
-                    g.strip_cellof[base + (size_t)(start + x)] = (uint8_t)((c - a) | (x == 0 ? 0x40 : 0) | (x == iw - 1 ? 0x80 : 0));
-                start += iw;
-                g.max_cell_interior = std::max(g.max_cell_interior, iw * (g.cells[c].ch - 6));
-            }
-            a = b;
-        }
-        i = j;
-    }
     g.pyr_bytes = off;
     g.cand_total = cand_off;
     g.kp_total = kp_off;

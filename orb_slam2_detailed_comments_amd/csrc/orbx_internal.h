@@ -29,15 +29,6 @@ struct OrbxFastGroup {
     int32_t ncell;
 };
 
-// One wave of k_fast_strip: a STRIP of up to ORBX_STRIP_MAXCELLS horizontally adjacent cells of one cell row (OrbxFastGroup
-// {cell0, ncell}) whose interiors together span at most ORBX_STRIP_COLS columns: lane l of the wave owns tile columns
-// 3l .. 3l+2 (three pixels per lane in 10-bit fields of one register), lanes 0 and 63 hold the 3-pixel ring margin.
-// strip_cellof[strip][tile column] = cell ordinal inside the strip (7 = no cell: ring margin, columns beyond the strip)
-// | 0x40 first interior column of its cell | 0x80 last interior column of its cell (NMS does not look across a seam).
-#define ORBX_STRIP_COLS 186
-#define ORBX_STRIP_TILE_COLS 192
-#define ORBX_STRIP_MAXCELLS 6
-
 // resize tap for one padded destination coordinate (border folded in by reflect-101)
 struct OrbxTap {
     int16_t s0, s1;  // source index of the two taps (already clamped)
@@ -69,9 +60,6 @@ struct OrbxGeom {
     OrbxLevelGeom lv[ORBX_MAX_LEVELS];
     std::vector<OrbxCell> cells;
     std::vector<OrbxFastGroup> fast_groups;
-    std::vector<OrbxFastGroup> fast_strips;     // k_fast_strip work items, level-major like the cells
-    std::vector<uint8_t> strip_cellof;          // ORBX_STRIP_TILE_COLS bytes per strip
-    int max_cell_interior = 0;                  // largest (cw-6)*(ch-6): corners one cell can produce
     std::vector<OrbxTap> taps;
     int64_t pyr_bytes = 0;     // per frame
     int64_t cand_total = 0;    // per frame

@@ -695,7 +695,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     gc.out_cap = L.cand_cap;
     orbx_wave_sync();
     if (dbg_stop == 1) continue;
-    const bool two_th = g.min_th != g.ini_th && dbg_stop != 5;   // (5: timing build, no threshold retry)
+    const bool two_th = g.min_th != g.ini_th;
     const bool colv = lane < niw;
     const bool second = lane >= iw0;
     const uint8_t *pc = cx.tile + 3 + (colv ? lane : 0);   // this lane's column, row 0
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
         }
         // ---- NMS
         int a0 = 0, a1 = 0;
-        if (dbg_stop >= 2 && dbg_stop != 5) { a0 = a1 = 1; } else
+        if (dbg_stop >= 2) { a0 = a1 = 1; } else
         if (!overflow) {
             fr_nms(cx, gc, s_corn, nctot, a0, a1);
         } else {
@@ -835,500 +835,6 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
     orbx_wave_sync();   // the next group overwrites tile / score / lists
   }
 #undef FR_PREFETCH
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_fast_strip: the same per-cell FAST-9/16 + score + NMS + threshold retry as k_fast_rows, reorganised around three pixels
-// per lane (round 3).  k_fast_rows spent 16 wave-instructions per 64-pixel row on the compass pre-test + compaction, ran its
-// ring / score / NMS rounds on the ~210 candidates / ~76 corners of ONE cell pair (64-lane rounds 82 % / 59 % full) and walked
-// every pair of cells as a separate work item.  Here:
-//   * one wave owns a STRIP of up to six horizontally adjacent cells (<= 186 interior columns).  Lane l holds tile columns
-//     3l..3l+2 of the current row as THREE 10-bit fields of one register (lanes 0 and 63 carry the 3-pixel ring margin), the
-//     column window of 7 rows rotates through seven such registers;
-//   * the compass pre-test (a 9-arc of the ring contains one pixel of every opposite pair: for some polarity BOTH pairs
-//     (r0, r8), (r4, r12) must hold a pixel beyond the threshold) is evaluated on the three pixels at once with plain 32-bit
-//     subtractions: field_f(U_k - (U_c + KH)) = 512 + r - c - th - 1 has bit 9 set exactly when r > c + th, fields cannot
-//     borrow from each other (every field stays in [1, 766]), and the horizontal pair r4 / r12 of a lane's three pixels IS the
-//     register of lane + 1 / lane - 1 (DPP wave shifts folded into the subtractions) -- 20 instructions per 186 pixels
-//     instead of 10 per 62.  The shifted operand is always the MINUEND (v_sub_u32_dpp): for the darker polarity the
-//     horizontal pair is tested on the complemented row (255 - pixel per field).  The natural form aL - dpp(C) compiles to
-//     v_subrev_u32_dpp, which on gfx950 returns dpp(src1) - src0, not src1 - dpp(src0) (tools/dpp_probe.hip;
-//     tests/test_abi.py checks that no such instruction is in the code object).  Cells that are switched off (threshold retry, columns beyond the strip) carry th = 255 in their
-//     fields, which no 8-bit difference exceeds;
-//   * ONE compaction per row (ballot of "any of my three pixels") into a list of (row, lane, 3 flags) entries; the entries are
-//     expanded to pixel codes afterwards (wave prefix sum), so the ring test, the score and the NMS run on the merged
-//     candidates of the whole strip in full 64-lane rounds;
-//   * the scores of the corners are kept beside the corner list and scattered into the TILE's own LDS bytes once the last
-//     ring test has read them (no second LDS image: 16 KB per wave instead of 27); a cell that comes out empty (4.6 % of the
-//     cells, reference :1519-1527) has the tile staged again for its minThFAST pass.
-// Candidate list overflow flushes through ring test + score as before; if the corners of a strip do not fit the corner
-// list, the strip falls back to one cell per pass (a cell's corners always fit: the host sizes the list by the largest cell).
-// ------------------------------------------------------------------------------------------------
-#ifndef FS_TP
-#define FS_TP 208             // LDS tile pitch: 13 x 16 bytes >= 192 tile columns + 3 alignment bytes
-#endif
-#define FS_LOADS 6            // register window of the tile prefetch: 6 loads x 4 rows x 13 pieces of 16 bytes = one band
-#define FS_FMASK 0x20080200u  // bit 9 of the three 10-bit fields
-#define FS_ONES 0x0ff3fcffu   // 255 in each of them
-#ifndef FS_WPS
-#define FS_WPS 4
-#endif
-typedef __attribute__((address_space(3))) uint32_t fs_lds_u32;
-
-struct FsCtx {
-    uint8_t *tile;           // LDS tile, byte (0,0) = sub-mat origin of the strip's first cell; re-used as the score map
-    uint8_t *tile0;          // its 16-byte aligned base (tile = tile0 + (x0 & 3))
-    uint32_t *ent;           // walk output: flags | row << 10 | lane   (ecap entries + one private dummy dword per lane)
-    uint16_t *list;          // candidate codes row << 8 | interior column (lcap); corners compacted in place (bit 15 = brighter ring)
-    uint16_t *corn;          // corners of the pass (ccap)
-    uint8_t *cscore;         // their scores
-    const uint8_t *cellof;   // tile column -> cell ordinal | seam flags (ORBX_STRIP_TILE_COLS)
-    uint2 *ctab;             // per cell: {offx | first interior column << 16, idx_in_level}
-    int *ccapv;              // per cell: slot_cap
-    int *hit;                // per cell: a survivor was seen in this pass
-    int ecap, lcap, ccap, lane;
-};
-
-// full 16-ring test of list[0..n) at threshold th (corners compacted in place to the front of the list), then the score of
-// every corner, appended with its code to the pass's corner list.  Returns false when that list cannot take them.
-__device__ __forceinline__ bool fs_ring_and_score(const FsCtx &c, int n, int th, int &nctot, int dbg_stop) {
-    const int ro[16] = {3 * FS_TP,      3 * FS_TP + 1,  2 * FS_TP + 2,  FS_TP + 3, 3,  -FS_TP + 3,
-                        -2 * FS_TP + 2, -3 * FS_TP + 1, -3 * FS_TP,     -3 * FS_TP - 1, -2 * FS_TP - 2,
-                        -FS_TP - 3,     -3,             FS_TP - 3,      2 * FS_TP - 2,  3 * FS_TP - 1};
-    int ncorn = 0;
-    for (int e0 = 0; e0 < n; e0 += 64) {
-        const int e = e0 + c.lane;
-        const bool valid = e < n;
-        const uint16_t code = valid ? c.list[e] : (uint16_t)(3 << 8);
-        const uint8_t *ptr = c.tile + (code >> 8) * FS_TP + 3 + (code & 0xff);
-        const int v = ptr[0];
-        const int hi = v + th, lo = v - th;
-        // ring masks by shift-in: mask = 2*mask + (compare) is one v_cmp + one v_addc per ring pixel and polarity
-        uint32_t bright = 0, dark = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int x = ptr[ro[k]];
-            asm("v_cmp_gt_i32 vcc, %2, %3\n\t"
-                "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
-                "v_cmp_lt_i32 vcc, %2, %4\n\t"
-                "v_addc_co_u32 %1, vcc, %1, %1, vcc"
-                : "+v"(bright), "+v"(dark)
-                : "v"(x), "v"(hi), "v"(lo)
-                : "vcc");
-        }
-        const bool cb = orbx_arc9(bright), cd = orbx_arc9(dark);
-        const bool corner = (int)valid & ((int)cb | (int)cd);
-        const unsigned long long m = orbx_ballot(corner);
-        if (corner) c.list[ncorn + orbx_wave_rank(m)] = (uint16_t)(code | (cb ? 0x8000u : 0u));   // index <= e: already read
-        ncorn += __popcll(m);
-    }
-    orbx_wave_sync();
-    if (nctot + ncorn > c.ccap) return false;
-    if (dbg_stop == 3) { nctot += ncorn; return true; }
-    // score = max over the 16 arcs of the min over the arc of the signed difference, minus 1 (cv::cornerScore<16>), own polarity only
-    for (int e = c.lane; e < ncorn; e += 64) {
-        const uint16_t code = c.list[e];
-        const int off = ((code >> 8) & 0x7f) * FS_TP + 3 + (code & 0xff);
-        const uint8_t *ptr = c.tile + off;
-        const fr_u16 flip = (code & 0x8000u) != 0 ? (fr_u16)0 : (fr_u16)0xff;
-        const fr_i16 v = (fr_i16)((fr_u16)ptr[0] ^ flip);
-        fr_i16 d[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = (fr_i16)((fr_i16)((fr_u16)ptr[ro[k]] ^ flip) - v);
-        fr_i16 a0 = (fr_i16)th;
-        fr_i16 m2[16], m4[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) m2[k] = fr_smin(d[k], d[(k + 1) & 15]);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) m4[k] = fr_smin(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a0 = fr_smax(a0, fr_smin(fr_smin(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
-        c.corn[nctot + e] = (uint16_t)(code & 0x7fffu);
-        c.cscore[nctot + e] = (uint8_t)(a0 - 1);
-    }
-    nctot += ncorn;
-    orbx_wave_sync();
-    return true;
-}
-
-struct FsOut {
-    uint2 *out;      // dense candidate array of this (frame, level)
-    int *cursor;     // its fill count
-    int out_cap;
-    int offy;        // i * hCell of the strip's cell row
-};
-
-// strict 3x3 NMS of corn[0..n) among the corners of the SAME cell; the score map is built in the band tile's bytes (every ring
-// test of the band has been made).  Only corners of tile rows [rlo, rhi) are decided here (the rows below belong to the next
-// band: their lower neighbours are not known yet); survivors go straight to the level's dense key array.
-__device__ __forceinline__ void fs_nms(const FsCtx &c, const FsOut &go, int n, int tile_rows, int rlo, int rhi, int yoff,
-                                       bool capped, int *nsk) {
-    for (int i = c.lane; i < (tile_rows * FS_TP + 15) / 16; i += 64) ((uint4 *)c.tile0)[i] = make_uint4(0, 0, 0, 0);
-    orbx_wave_sync();
-    for (int e = c.lane; e < n; e += 64) {
-        const uint16_t code = c.corn[e];
-        c.tile[(code >> 8) * FS_TP + 3 + (code & 0xff)] = c.cscore[e];
-    }
-    orbx_wave_sync();
-    for (int e0 = 0; e0 < n; e0 += 64) {
-        const int e = e0 + c.lane;
-        const uint16_t code = e < n ? c.corn[e] : (uint16_t)(3 << 8);
-        const int col = code & 0xff, lr = code >> 8;
-        const bool valid = e < n && lr >= rlo && lr < rhi;
-        const uint8_t *sp = c.tile + lr * FS_TP + 3 + col;
-        const int sc = sp[0];
-        int l0 = sp[-FS_TP - 1], l1 = sp[-1], l2 = sp[FS_TP - 1];
-        int r0 = sp[-FS_TP + 1], r1 = sp[1], r2 = sp[FS_TP + 1];
-        const int u = sp[-FS_TP], dn = sp[FS_TP];
-        const int cf = c.cellof[3 + col];
-        const int kc = cf & 7;
-        // the score map is shared by the cells of the strip: the neighbours across a seam belong to another cv::FAST call
-        const bool seam_l = (cf & 0x40) != 0, seam_r = (cf & 0x80) != 0;
-        l0 = seam_l ? 0 : l0; l1 = seam_l ? 0 : l1; l2 = seam_l ? 0 : l2;
-        r0 = seam_r ? 0 : r0; r1 = seam_r ? 0 : r1; r2 = seam_r ? 0 : r2;
-        const bool keep = (int)valid & (int)(sc > l0) & (int)(sc > l1) & (int)(sc > l2) & (int)(sc > r0) & (int)(sc > r1) &
-                          (int)(sc > r2) & (int)(sc > u) & (int)(sc > dn);
-        bool ok = keep;
-        if (capped) {   // max_cand_per_cell cut the exact NMS worst case: a cell reports its first slot_cap survivors (emission order)
-            int slot = 0;
-#pragma unroll
-            for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) {
-                const unsigned long long mk = orbx_ballot(keep && kc == k);
-                if (kc == k) slot = nsk[k] + orbx_wave_rank(mk);
-                nsk[k] += __popcll(mk);
-            }
-            ok = keep && slot < c.ccapv[kc];
-        }
-        const unsigned long long mok = orbx_ballot(ok);
-        if (orbx_ballot(keep) != 0ull) {
-            if (keep) c.hit[kc] = 1;
-            int base = 0;
-            if (c.lane == 0 && mok != 0ull) base = atomicAdd(go.cursor, (int)__popcll(mok));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const int pos = base + orbx_wave_rank(mok);
-            if (ok && pos < go.out_cap) {
-                const uint2 ct = c.ctab[kc];
-                const int lx = 3 + col - (int)(ct.x >> 16), ly = lr + yoff;
-                uint2 o;
-                o.x = (uint32_t)(lx + (int)(ct.x & 0xffffu)) | ((uint32_t)(ly + go.offy) << 12) | ((uint32_t)sc << 24);
-                o.y = (ct.y << 12) | ((uint32_t)ly << 6) | (uint32_t)lx;   // emission order key
-                go.out[pos] = o;
-            }
-        }
-    }
-    orbx_wave_sync();
-}
-
-__global__ __launch_bounds__(64, FS_WPS) void k_fast_strip(DGeom g, const OrbxCell *__restrict__ cells,
-                                                           const OrbxFastGroup *__restrict__ strips,
-                                                           const uint8_t *__restrict__ strip_cellof,
-                                                           const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
-                                                           int *__restrict__ cand_cursor, int *__restrict__ status, int rows,
-                                                           int bhmax, int ecap, int lcap, int ccap, int nstrips, int spw,
-                                                           int capped, int dbg_stop) {
-    // dbg_stop (ORBX_FAST_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS; results are wrong unless 0): 1 = after
-    // staging, 2 = after the pre-test walk, 3 = after the ring test, 4 = before NMS.  The shipped library pins it to 0.
-#ifndef ORBX_TIMING_KNOBS
-    dbg_stop = 0;
-#endif
-    extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
-    // tile[rows*TP] | ent u32[ecap + 64] | list u16[lcap] | corn u16[ccap] | cscore u8[ccap] | cellof u8[192] | ctab uint2[8] | ccapv int[8] | hit int[8]
-    uint8_t *s_tile = fast_smem;
-    uint32_t *s_ent = (uint32_t *)(s_tile + rows * FS_TP);
-    uint16_t *s_list = (uint16_t *)(s_ent + ecap + 64);
-    uint16_t *s_corn = s_list + lcap;
-    uint8_t *s_cscore = (uint8_t *)(s_corn + ccap);
-    uint8_t *s_cellof = s_cscore + ccap;
-    uint2 *s_ctab = (uint2 *)(s_cellof + ORBX_STRIP_TILE_COLS);
-    int *s_ccapv = (int *)(s_ctab + 8);
-    int *s_hit = s_ccapv + 8;
-    const int lane = threadIdx.x;
-    const int f = blockIdx.x;   // frame fastest: all strips of one frame share one XCD's L2
-    const int g0 = blockIdx.y * spw;
-    const int ng = min(spw, nstrips - g0);
-    // A strip is walked in BANDS of at most bhmax interior rows (tile = band + 6 ring rows <= `rows`): the LDS footprint of a wave
-    // is a third of the whole strip's, which is what buys the kernel its waves per CU.  Staging: a lane loads 16 bytes, 13 lanes
-    // cover a tile row (208 bytes), 4 rows per load, FS_LOADS loads = 24 rows in registers (the NEXT band's, or the next strip's
-    // first band, requested while this band is processed).  Row offsets are 32-bit adds from the first row's offset, clamped to
-    // the band's last row; the piece offset is clamped to the level's last 16 bytes of a row (pieces beyond the level's width hold
-    // columns no cell reaches).
-    const int rq = (lane * 5) >> 6, dq = lane - 13 * rq;   // lane / 13, lane % 13  (lanes 52..63: rq = 4, idle)
-    // (named registers, not an array: the array form of this window ends up in scratch memory)
-#define FS_FOR_LOADS(M) M(0) M(1) M(2) M(3) M(4) M(5)
-    static_assert(FS_LOADS == 6, "FS_FOR_LOADS lists the loads");
-#define FS_DECL(k) uint4 tv##k;
-    FS_FOR_LOADS(FS_DECL)
-#undef FS_DECL
-    uint32_t tcf = 0;
-    const uint8_t *fbase = pyr + (long long)f * g.pyr_bytes;
-    // bands of a strip whose cells are `ch` rows tall: nb bands of bh interior rows (the last one takes what is left)
-#define FS_BANDS(ch, nb, bh) const int nb = max(1, ((ch) - 6 + bhmax - 1) / bhmax), bh = ((ch) - 6 + nb - 1) / nb;
-    // first tile row (cell coordinates) and number of tile rows of band b
-#define FS_BAND_ROWS(ch, bh, b, trow0, tnrows) const int trow0 = (b) * (bh), tnrows = min((ch), trow0 + (bh) + 6) - trow0;
-#define FS_ROW_OFFSETS(CELL, LV, trow0, tnrows, o, olast, vpitch4)                                                         \
-        uint32_t vpitch4 = (uint32_t)(4 * LV.pitch);                                                                      \
-        asm("" : "+v"(vpitch4));   /* in a VGPR: a VOP2 add with an SGPR source issues at the slow rate */                  \
-        const uint32_t xoff_ = (uint32_t)min((CELL.x0 & ~3) + 16 * dq, LV.pitch - 16);                                    \
-        const uint32_t olast = (uint32_t)__mul24((int)CELL.y0 + (trow0) + (tnrows) - 1, LV.pitch) + xoff_;                \
-        uint32_t o = (uint32_t)__mul24((int)CELL.y0 + (trow0) + min(rq, 3), LV.pitch) + xoff_;
-#define FS_LOAD1(k) tv##k = *(const uint4 *)(srcn + min(o, olast)); o += vpitch4;
-    // the item the registers hold: band pf_b of strip pf_s (of this wave's strips)
-    int pf_s = 0, pf_b = 0;
-    OrbxFastGroup pf_grp = strips[g0];
-    OrbxCell pf_c0 = cells[pf_grp.cell0];
-#define FS_PREFETCH()                                                                                                     \
-    {                                                                                                                     \
-        const DLevel &Ln = g.lv[pf_c0.level];                                                                            \
-        const uint8_t *srcn = fbase + Ln.off;                                                                             \
-        FS_BANDS(pf_c0.ch, nbn, bhn)                                                                                      \
-        FS_BAND_ROWS(pf_c0.ch, bhn, pf_b, trow0n, tnrowsn)                                                                \
-        FS_ROW_OFFSETS(pf_c0, Ln, trow0n, tnrowsn, o, olast, vpitch4)                                                     \
-        FS_FOR_LOADS(FS_LOAD1)                                                                                            \
-        tcf = ((const uint32_t *)strip_cellof)[(size_t)(g0 + pf_s) * (ORBX_STRIP_TILE_COLS / 4) + min(lane, ORBX_STRIP_TILE_COLS / 4 - 1)]; \
-    }
-    // band (c0, b) straight from memory (threshold retry, sub-band after a corner-list overflow): all loads in flight, then the stores
-#define FS_RESTAGE(c0, L, trow0, tnrows)                                                                                  \
-    {                                                                                                                     \
-        const uint8_t *src = fbase + L.off;                                                                               \
-        FS_ROW_OFFSETS(c0, L, trow0, tnrows, o, olast, vpitch4)                                                           \
-        uint4 t[FS_LOADS];                                                                                                \
-        _Pragma("unroll") for (int k = 0; k < FS_LOADS; ++k) { t[k] = *(const uint4 *)(src + min(o, olast)); o += vpitch4; } \
-        _Pragma("unroll") for (int k = 0; k < FS_LOADS; ++k)                                                              \
-            if (rq < 4 && 4 * k + rq < (tnrows)) *(uint4 *)(s_tile + (4 * k + rq) * FS_TP + 16 * dq) = t[k];              \
-        orbx_wave_sync();                                                                                                 \
-    }
-    FS_PREFETCH()
-  for (int gi = 0; gi < ng; ++gi) {
-    // (pf_grp / pf_c0 describe this strip: they were loaded with the request for its first band, a band or a strip ago)
-    const OrbxFastGroup grp = pf_grp;
-    const OrbxCell c0 = pf_c0;
-    const DLevel &L = g.lv[c0.level];
-    const int ncell = grp.ncell;
-    const int yend = c0.ch - 3;
-    FS_BANDS(c0.ch, nb, bh)
-    FsCtx cx;
-    cx.tile = s_tile + (c0.x0 & 3);
-    cx.tile0 = s_tile;
-    cx.ent = s_ent; cx.list = s_list; cx.corn = s_corn; cx.cscore = s_cscore; cx.cellof = s_cellof;
-    cx.ctab = s_ctab; cx.ccapv = s_ccapv; cx.hit = s_hit;
-    cx.ecap = ecap; cx.lcap = lcap; cx.ccap = ccap; cx.lane = lane;
-    FsOut go;
-    go.out = cand + (long long)f * g.cand_total + L.cand_begin;
-    go.cursor = cand_cursor + f * g.nlevels + c0.level;
-    go.out_cap = L.cand_cap;
-    go.offy = c0.offy;
-    const bool two_th = g.min_th != g.ini_th && dbg_stop != 5;   // (5: timing build, no threshold retry)
-    const uint8_t *pc = cx.tile + 3 * lane;                  // this lane's three columns, tile row 0
-    unsigned act_ini = (1u << ncell) - 1u, act_min = 0u;     // cells still to be detected at iniThFAST / minThFAST
-    int nsk[ORBX_STRIP_MAXCELLS];                            // survivors per cell (capped mode)
-#pragma unroll
-    for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) nsk[k] = 0;
-    while ((act_ini | act_min) != 0u) {
-        const unsigned act = act_ini != 0u ? act_ini : act_min;
-        const int th = act_ini != 0u ? g.ini_th : g.min_th;
-        uint32_t KH = 0, KL = 0;   // per-lane threshold constants (set once the strip's column table is in LDS)
-        int ncarry = 0;            // corners of the two tile rows above the current rows, kept for the next NMS
-        for (int b = 0; b < nb; ++b) {
-            FS_BAND_ROWS(c0.ch, bh, b, trow0, tnrows)   // tile row r <-> cell row trow0 + r
-            const int ba = 3 + b * bh, bb = min(yend, ba + bh);   // interior rows of the band (cell coordinates)
-            int span = bb - ba;
-            for (int wa = ba; wa < bb;) {
-                const int wb = min(bb, wa + span);
-                // ---- stage the band's tile
-                // (the registers hold band pf_b of strip pf_s: this band on the strip's first pass -- every band's first staging
-                // requests the item after it; a threshold-retry pass and the second half of a split band come from memory)
-                if (pf_s == gi && pf_b == b && wa == ba) {
-                    uint8_t *trow = s_tile + rq * FS_TP + 16 * dq;
-#define FS_STORE1(k) if (rq < 4 && 4 * k + rq < tnrows) *(uint4 *)(trow + 4 * k * FS_TP) = tv##k;
-                    FS_FOR_LOADS(FS_STORE1)
-#undef FS_STORE1
-                    if (b == 0) {   // per-strip tables
-                        if (lane < ORBX_STRIP_TILE_COLS / 4) ((uint32_t *)s_cellof)[lane] = tcf;
-                        if (lane < ncell) {
-                            const OrbxCell cj = cells[grp.cell0 + lane];
-                            s_ctab[lane] = make_uint2((uint32_t)(uint16_t)cj.offx | ((uint32_t)(cj.x0 - c0.x0) << 16), (uint32_t)cj.idx_in_level);
-                            s_ccapv[lane] = cj.slot_cap;
-                        }
-                        if (lane < ORBX_STRIP_MAXCELLS) s_hit[lane] = 0;
-                    }
-                    // request the next item: the next band of this strip, or the first band of the wave's next strip
-                    if (b + 1 < nb) { pf_b = b + 1; FS_PREFETCH() }
-                    else if (gi + 1 < ng) { pf_s = gi + 1; pf_b = 0; pf_grp = strips[g0 + pf_s]; pf_c0 = cells[pf_grp.cell0]; FS_PREFETCH() }
-                    orbx_wave_sync();
-                } else {
-                    FS_RESTAGE(c0, L, trow0, tnrows)
-                }
-                if (dbg_stop == 1) { wa = wb; continue; }
-                if (b == 0 && wa == ba) {
-                    // a field whose column is outside the strip or in a cell that is not part of this pass carries th = 255 (no
-                    // 8-bit difference exceeds it): the pre-test needs no lane or column mask
-                    KH = 0; KL = 0;
-#pragma unroll
-                    for (int fq = 0; fq < 3; ++fq) {
-                        const int kc = s_cellof[3 * lane + fq] & 7;
-                        const int thf = ((act >> kc) & 1u) ? th : 255;
-                        KH += (uint32_t)(thf + 1 - 512) << (10 * fq);
-                        KL += (uint32_t)(511 - thf) << (10 * fq);
-                    }
-                }
-                // ---- detect the corners of cell rows [wa, wb): tile rows [wa - trow0, wb - trow0)
-                int nctot = ncarry;
-                bool overflow = false;
-                int y = wa - trow0;
-                const int ye = wb - trow0;
-                const uint32_t ent0 = (uint32_t)(uintptr_t)(fs_lds_u32 *)s_ent;
-                const uint32_t dummy = ent0 + 4u * (uint32_t)ecap + 4u * (uint32_t)lane;
-                bool slow = false;   // a 7-row chunk overran the entry list: single rows for the rest of these rows
-                while (y < ye && !overflow) {
-                    // ---- compass pre-test, one row per step, three pixels per lane (see the header)
-                    const uint8_t *pr = pc + y * FS_TP;
-#define FS_PACK(p) ((uint32_t)(p)[0] | ((uint32_t)(p)[1] << 10) | ((uint32_t)(p)[2] << 20))
-                    uint32_t w0 = FS_PACK(pr - 3 * FS_TP), w1 = FS_PACK(pr - 2 * FS_TP), w2 = FS_PACK(pr - FS_TP), w3 = FS_PACK(pr),
-                             w4 = FS_PACK(pr + FS_TP), w5 = FS_PACK(pr + 2 * FS_TP), w6;
-                    uint32_t nb_ = ent0;
-                    uint32_t code = (uint32_t)((y << 10) | lane);
-                    // software-pipelined: the three LDS bytes of row y+4 are requested before row y is evaluated; the row after
-                    // the last one is read but never used (it lies inside the LDS allocation)
-                    uint32_t nx0 = pr[3 * FS_TP], nx1 = pr[3 * FS_TP + 1], nx2 = pr[3 * FS_TP + 2];
-#define FS_STEP(R8, C, R0)                                                                                              \
-                    {                                                                                                   \
-                        R0 = nx0 | (nx1 << 10) | (nx2 << 20);                                                           \
-                        pr += FS_TP;                                                                                    \
-                        nx0 = pr[3 * FS_TP]; nx1 = pr[3 * FS_TP + 1]; nx2 = pr[3 * FS_TP + 2];                          \
-                        asm("" : "+v"(nx0), "+v"(nx1), "+v"(nx2));                                                      \
-                        const uint32_t aH = C + KH, aL = C + KL;                                                        \
-                        const uint32_t vc = FS_ONES - C, aV = vc + KH;   /* the row complemented: darker = brighter there */ \
-                        const uint32_t cr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xf, 0xf, true);    \
-                        const uint32_t cl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xf, 0xf, true);    \
-                        const uint32_t vr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vc, 0x130, 0xf, 0xf, true);   \
-                        const uint32_t vl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vc, 0x138, 0xf, 0xf, true);   \
-                        const uint32_t bb_ = ((R0 - aH) | (R8 - aH)) & ((cr - aH) | (cl - aH));                         \
-                        const uint32_t dd_ = ((aL - R0) | (aL - R8)) & ((vr - aV) | (vl - aV));                         \
-                        const uint32_t cc = (bb_ | dd_) & FS_FMASK;                                                     \
-                        const bool cnd = cc != 0u;                                                                      \
-                        const unsigned long long m = orbx_ballot(cnd);                                                  \
-                        *(fs_lds_u32 *)(uintptr_t)(cnd ? min(nb_ + 4u * (uint32_t)orbx_wave_rank(m), dummy) : dummy) = cc | code; \
-                        nb_ += 4u * (uint32_t)__popcll(m);                                                              \
-                        code += 0x400u;                                                                                 \
-                    }
-                    // Chunks of 7 rows are walked OPTIMISTICALLY: a row can add up to 62 entries but adds about 12, and reserving
-                    // the worst case for seven rows would double the list.  A store beyond the list lands in the lane's dummy
-                    // slot (the address is clamped: dummy = list end + lane); if the cursor shows that happened, the chunk's
-                    // entries are dropped, what was there before is flushed and the rows are walked again one at a time.
-                    const uint32_t ent_end = ent0 + 4u * (uint32_t)ecap;
-                    bool dropped = false;
-                    while (y + 7 <= ye && !slow && nb_ + 256u <= ent_end) {
-                        const uint32_t nb_save = nb_;
-                        FS_STEP(w0, w3, w6)
-                        FS_STEP(w1, w4, w0)
-                        FS_STEP(w2, w5, w1)
-                        FS_STEP(w3, w6, w2)
-                        FS_STEP(w4, w0, w3)
-                        FS_STEP(w5, w1, w4)
-                        FS_STEP(w6, w2, w5)
-                        if (nb_ > ent_end) { nb_ = nb_save; slow = true; dropped = true; break; }
-                        y += 7;
-                    }
-                    if (!dropped)   // (after a dropped chunk: flush what was there, prime the window again, then single rows)
-                    while (y < ye && nb_ + 256u <= ent_end && (slow || y + 7 > ye)) {
-                        FS_STEP(w0, w3, w6)
-                        w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6;
-                        ++y;
-                    }
-#undef FS_STEP
-#undef FS_PACK
-                    const int ne = (int)((nb_ - ent0) >> 2);
-                    orbx_wave_sync();
-                    if (dbg_stop == 2) { if (ne == 12345) cand_cursor[0] = ne; continue; }
-                    // ---- entries -> pixel codes (order kept: row-major over the strip), ring test + score in full rounds
-                    int nl = 0;
-                    for (int e0 = 0; e0 < ne && !overflow; e0 += 64) {
-                        const int e = e0 + lane;
-                        const uint32_t en = e < ne ? s_ent[e] : 0u;
-                        const int f0 = (en >> 9) & 1, f1 = (en >> 19) & 1, f2 = (en >> 29) & 1;
-                        const int cnt = f0 + f1 + f2;
-                        const int incl = orbx_wave_scan(cnt);
-                        const int tot = __builtin_amdgcn_readlane(incl, 63);
-                        if (nl + tot > lcap) {   // the list cannot take this chunk's pixels (<= 192): ring test + score what it holds
-                            overflow = !fs_ring_and_score(cx, nl, th, nctot, dbg_stop);
-                            nl = 0;
-                            if (overflow) break;
-                        }
-                        const uint32_t cb = (((en >> 10) & 0x7fu) << 8) + 3u * (en & 63u) - 3u;
-                        uint16_t *lp = s_list + nl + incl - cnt;
-                        if (f0) { *lp = (uint16_t)cb; ++lp; }
-                        if (f1) { *lp = (uint16_t)(cb + 1u); ++lp; }
-                        if (f2) { *lp = (uint16_t)(cb + 2u); }
-                        nl += tot;
-                    }
-                    orbx_wave_sync();
-                    if (!overflow && nl > 0) overflow = !fs_ring_and_score(cx, nl, th, nctot, dbg_stop);
-                }
-                if (overflow) {
-                    // the corners of these rows do not fit the corner list: take half the rows (the tile is intact: NMS has
-                    // not run).  One row with the two rows carried above it always fits (host: ccap >= 3 x strip width).
-                    if (wb - wa <= 1) { if (lane == 0) atomicMax(&status[f], (int)ORBX_CAPACITY); wa = wb; ncarry = 0; }
-                    else span = (wb - wa + 1) >> 1;
-                    continue;
-                }
-                if (dbg_stop >= 2 && dbg_stop != 5) {
-                    if (lane < ORBX_STRIP_MAXCELLS) s_hit[lane] = 1;
-                    wa = wb; ncarry = 0;
-                    orbx_wave_sync();
-                    continue;
-                }
-                // ---- NMS of the rows whose neighbours are all known: [wa - 1, wb - 1) ([.., wb) on the strip's last rows)
-                const bool last = wb == yend;
-                fs_nms(cx, go, nctot, tnrows, wa - 1 - trow0, (last ? wb : wb - 1) - trow0, trow0, capped != 0, nsk);
-                // ---- corners of the last two rows go on to the next NMS, re-based to the tile they will be scattered into
-                ncarry = 0;
-                if (!last) {
-                    const int klo = wb - 2 - trow0;
-                    const int rebase = (wb == bb) ? bh : 0;   // the next band's tile starts bh rows further down
-                    for (int e0 = 0; e0 < nctot; e0 += 64) {
-                        const int e = e0 + lane;
-                        const uint16_t code = e < nctot ? s_corn[e] : (uint16_t)0;
-                        const uint8_t sc = e < nctot ? s_cscore[e] : (uint8_t)0;
-                        const bool kp = e < nctot && (code >> 8) >= klo;
-                        const unsigned long long m = orbx_ballot(kp);
-                        if (kp) {   // index <= e: this round's entries are already in registers
-                            const int d = ncarry + orbx_wave_rank(m);
-                            s_corn[d] = (uint16_t)(code - (rebase << 8));
-                            s_cscore[d] = sc;
-                        }
-                        ncarry += __popcll(m);
-                    }
-                    orbx_wave_sync();
-                }
-                wa = wb;
-            }
-        }
-        unsigned hits = 0u;
-#pragma unroll
-        for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) hits |= (k < ncell && s_hit[k] != 0) ? (1u << k) : 0u;
-        hits = (unsigned)__builtin_amdgcn_readfirstlane((int)hits);   // (wave-uniform by construction: keeps the pass loop scalar)
-        orbx_wave_sync();
-        if (lane < ORBX_STRIP_MAXCELLS) s_hit[lane] = 0;
-        // vKeysCell.empty() -> that cell alone repeats with minThFAST (:1519-1527)
-        if (act_ini != 0u) { act_ini = 0u; if (two_th) act_min = act & ~hits; }
-        else act_min = 0u;
-        orbx_wave_sync();
-    }
-    if (capped) {   // more survivors than a cell may report: reported, not silent
-        bool over = false;
-#pragma unroll
-        for (int k = 0; k < ORBX_STRIP_MAXCELLS; ++k) over = over || (k < ncell && nsk[k] > s_ccapv[k]);
-        if (over && lane == 0) atomicMax(&status[f], (int)ORBX_CAPACITY);
-    }
-    orbx_wave_sync();   // the next strip overwrites tile / lists / tables
-  }
-#undef FS_PREFETCH
-#undef FS_RESTAGE
-#undef FS_LOAD1
-#undef FS_FOR_LOADS
-#undef FS_ROW_OFFSETS
-#undef FS_BANDS
-#undef FS_BAND_ROWS
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2906,32 +2412,12 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
     if (ngroups <= 0) return;
     lcap = (max(lcap, 64) + 1) & ~1;
     max_ch = (max_ch + 3) & ~3;   // tile and score map sizes multiples of 16 bytes
-#ifndef FR_PAD
-#define FR_PAD 0
-#endif
-    const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256 + FR_PAD;
+    const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256;
     // groups per wave: FR_GPW when the launch has waves to spare (the second group's tile is prefetched while the first
     // is processed); one per wave for small batches, where the serial length of a wave is what the caller waits for
     const int gpw = (long long)B * ngroups >= 16384 ? FR_GPW : 1;
     hipLaunchKernelGGL(k_fast_rows, dim3(B, (ngroups + gpw - 1) / gpw), dim3(64), smem, s, g, cells, groups, pyr, cand,
                        cand_cursor, status, max_ch, lcap, ngroups, gpw, dbg_stop);
-}
-void orbx_launch_fast_strip(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *strips,
-                            const uint8_t *strip_cellof, int nstrips, const uint8_t *pyr, uint2 *cand, int *cand_cursor,
-                            int *status, int bhmax, int ecap, int lcap, int ccap, int capped, int dbg_stop) {
-    if (nstrips <= 0) return;
-    bhmax = min(max(bhmax, 1), 4 * FS_LOADS - 6);   // a band's tile (band + 6 ring rows) must fit the register window
-    ecap = (max(ecap, 64) + 1) & ~1;
-    lcap = (max(lcap, 192) + 3) & ~3;
-    ccap = (max(ccap, 3 * ORBX_STRIP_TILE_COLS) + 7) & ~7;   // one row + the two rows carried above it always fit
-    const int rows = (bhmax + 6 + 3) & ~3;
-    const size_t smem = (size_t)rows * FS_TP + (size_t)4 * (ecap + 64) + (size_t)2 * lcap + (size_t)3 * ccap +
-                        ORBX_STRIP_TILE_COLS + 8 * sizeof(uint2) + 16 * sizeof(int);
-    // strips per wave: 2 when the launch has waves to spare; one per wave for small batches, where the serial length of a
-    // wave is what the caller waits for (the bands of one strip already overlap their loads with the work)
-    const int spw = (long long)B * nstrips >= 8192 ? 2 : 1;
-    hipLaunchKernelGGL(k_fast_strip, dim3(B, (nstrips + spw - 1) / spw), dim3(64), smem, s, g, cells, strips, strip_cellof, pyr,
-                       cand, cand_cursor, status, rows, bhmax, ecap, lcap, ccap, nstrips, spw, capped, dbg_stop);
 }
 void orbx_launch_undistort(hipStream_t s, int B, int max_n, int cap, const double *K4, const double *k14, int identity,
                            const orbx_keypoint *kps, const int *counts, orbx_keypoint *out) {

@@ -17,9 +17,6 @@ void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, con
 void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *groups,
                            int ngroups, const uint8_t *pyr, uint2 *cand, int *cand_cursor, int *status, int max_ch, int lcap,
                            int dbg_stop);
-void orbx_launch_fast_strip(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *strips,
-                            const uint8_t *strip_cellof, int nstrips, const uint8_t *pyr, uint2 *cand, int *cand_cursor,
-                            int *status, int bhmax, int ecap, int lcap, int ccap, int capped, int dbg_stop);
 void orbx_launch_undistort(hipStream_t s, int B, int max_n, int cap, const double *K4, const double *k14, int identity,
                            const orbx_keypoint *kps, const int *counts, orbx_keypoint *out);
 void orbx_launch_bow_transform(hipStream_t s, int B, int max_n, const int *child_begin, const uint32_t *child_ids,

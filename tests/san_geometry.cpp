@@ -45,29 +45,6 @@ static void one(int w, int h, int nf, float sf, int nl) {
         const OrbxCell &a = g.cells[(size_t)G.cell0], &b = g.cells[(size_t)G.cell0 + G.ncell - 1];
         CHECK(a.level == b.level && a.y0 == b.y0 && b.x0 + b.cw - a.x0 - 6 <= 64 + ORBX_FAST_XCOLS);
     }
-    // strips of k_fast_strip: every cell in exactly one strip, in order; cells adjacent; interior columns fit the wave; the
-    // column -> cell table names the right cell with the seam flags on its first / last interior column
-    size_t next = 0;
-    CHECK(g.strip_cellof.size() == g.fast_strips.size() * ORBX_STRIP_TILE_COLS);
-    for (size_t si = 0; si < g.fast_strips.size(); ++si) {
-        const OrbxFastGroup &G = g.fast_strips[si];
-        CHECK((size_t)G.cell0 == next && G.ncell >= 1 && G.ncell <= ORBX_STRIP_MAXCELLS);
-        next += (size_t)G.ncell;
-        const OrbxCell &a = g.cells[(size_t)G.cell0], &b = g.cells[(size_t)G.cell0 + G.ncell - 1];
-        CHECK(a.level == b.level && a.y0 == b.y0 && a.ch == b.ch && b.x0 + b.cw - a.x0 - 6 <= ORBX_STRIP_COLS);
-        const uint8_t *t = &g.strip_cellof[si * ORBX_STRIP_TILE_COLS];
-        CHECK(t[0] == 7 && t[1] == 7 && t[2] == 7);
-        int col = 3;
-        for (int k = 0; k < G.ncell; ++k) {
-            const OrbxCell &C = g.cells[(size_t)G.cell0 + k];
-            CHECK(C.x0 - a.x0 == col - 3 && C.y0 == a.y0 && C.ch == a.ch && C.level == a.level);
-            CHECK((C.cw - 6) * (C.ch - 6) <= g.max_cell_interior);
-            for (int x = 0; x < C.cw - 6; ++x, ++col)
-                CHECK(t[col] == (uint8_t)(k | (x == 0 ? 0x40 : 0) | (x == C.cw - 7 ? 0x80 : 0)));
-        }
-        for (; col < ORBX_STRIP_TILE_COLS; ++col) CHECK(t[col] == 7);
-    }
-    CHECK(next == g.cells.size());
 }
 
 int main() {

@@ -71,3 +71,30 @@ def test_no_gpu_fails_loudly(built_lib):
     with pytest.raises(OrbxError) as e:
         ORBextractor()
     assert e.value.status == _capi.NO_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def _device_disassembly(lib):
+    """gfx950 disassembly of the code object embedded in the shared library (roc-obj-ls / roc-obj-extract + llvm-objdump)"""
+    import shutil, subprocess, tempfile
+    bundler = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    if not all(os.path.exists(t) for t in (bundler, objdump, objcopy)):
+        pytest.skip("ROCm LLVM tools not found")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "gfx950.co")
+        subprocess.check_call([objcopy, "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(d, "copy.so")])
+        subprocess.check_call([bundler, "--unbundle", "--type=o", f"--input={fat}", f"--output={co}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"])
+        return subprocess.run([objdump, "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
+
+
+def test_no_dpp_fused_reversed_operand_instruction(built_lib):
+    """On gfx950 `v_subrev_u32_dpp vdst, src0, src1` returns dpp(src1) - src0, not src1 - dpp(src0) as the ISA text and the
+    compiler's DPP combiner (which folds `x - dpp(y)` into it) assume (tools/dpp_probe.hip; profiles/r03_fast_strip_experiment.md:
+    round 3's strip kernel lost half of its dark-polarity candidates to it).  No kernel of the library may contain a
+    DPP-fused instruction of the reversed-operand family; plain DPP moves and commutative / forward DPP arithmetic are fine."""
+    asm = _device_disassembly(built_lib)
+    assert "v_mov_b32_dpp" in asm and "s_endpgm" in asm          # the disassembly is the library's (its scans use DPP moves)
+    bad = sorted(set(re.findall(r"\bv_\w*rev\w*_dpp\b", asm)))
+    assert not bad, f"DPP-fused reversed-operand instructions in the code object: {bad}"
