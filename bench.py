@@ -108,6 +108,14 @@ def committed_counters(kind, cfg_name, B, W, H, NF):
 def cpu_baseline(frames, right, nfeatures, stereo, mb, mbf, budget_s=20.0):
     """single-thread CPU oracle (port of the reference path) on a bounded sample of the same frames, pinned to one core"""
     import oracle
+    # the reference's own build flags (/root/reference/CMakeLists.txt:10-11: -O3 -march=native), compiled HERE for this host's
+    # cores; byte-identical to the -O2 parity build (tests/test_oracle_native_flags.py).  Falls back to the parity build.
+    flags = "-O2 -ffp-contract=off"
+    try:
+        os.environ["ORB_ORACLE_LIB"] = oracle.orb_oracle.build_native()
+        flags = oracle.orb_oracle.NATIVE_FLAGS
+    except Exception:
+        os.environ.pop("ORB_ORACLE_LIB", None)
     try:
         os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[-1]})   # SURVEY 8(d): taskset -c <core>
         pinned = True
@@ -132,7 +140,7 @@ def cpu_baseline(frames, right, nfeatures, stereo, mb, mbf, budget_s=20.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return n / dt, n, pinned
+    return n / dt, n, pinned, flags
 
 
 def main():
@@ -387,8 +395,8 @@ def main():
                                     "peak": 5000.0, "unit": "TOP/s", "frac": round(m_ops / (m_us * 1e-6) / 1e12 / 5000.0, 4),
                                     "avg_launch_us": round(m_us, 2)}
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only (the other ranks would idle through it)
-            cfps, nsample, pinned = cpu_baseline(frames, right, NF, stereo, mb, mbf)
-            out["cpu_baseline"] = {"value": round(cfps, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            cfps, nsample, pinned, cflags = cpu_baseline(frames, right, NF, stereo, mb, mbf)
+            out["cpu_baseline"] = {"value": round(cfps, 2), "unit": "frames/s", "cores": 1, "kind": "port", "flags": cflags,
                                    "sample": f"{nsample} {'stereo frames' if stereo else 'frames'} of the same synthetic stream, "
                                              f"single-thread CPU oracle (extract{' x2 + ComputeStereoMatches' if stereo else ' + brute-force match'}), "
                                              f"{'pinned to one core' if pinned else 'not pinned'}, host has {os.cpu_count()} cores"}

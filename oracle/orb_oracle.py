@@ -25,6 +25,16 @@ def build(force=False):
     return so
 
 
+NATIVE_FLAGS = "-O3 -march=native -ffp-contract=off"
+
+
+def build_native():
+    """the same sources with the reference's own optimisation flags (CMakeLists.txt:10-11), built on THIS machine (-march=native);
+    select it for a process with ORB_ORACLE_LIB=<path> before the first oracle call"""
+    subprocess.check_call(["make", "-C", _HERE, "-B", "_native/liborb_oracle_native.so"], stdout=subprocess.DEVNULL)
+    return os.path.join(_HERE, "_native", "liborb_oracle_native.so")
+
+
 def lib():
     global _LIB
     if _LIB is None:
