@@ -36,7 +36,7 @@ from orb_slam2_detailed_comments_amd import sharding
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SCLK_PEAK_HZ = 2.4e9    # same guide: max clock 2400 MHz
 N_SIMD = 1024           # 256 CUs x 4 SIMD-32
-PROFILE_TAG = "r02"     # profiles/<tag>_traffic.json, profiles/<tag>_sq.json
+PROFILE_TAG = "r03"     # profiles/<tag>_traffic.json, profiles/<tag>_sq.json
 
 CONFIGS = {   # name: (width, height, nfeatures, frames or pairs per GPU per step, stereo, mb, mbf)
     # batch sizes: large enough that launch boundaries and the drain of each kernel stop showing (tools/batch_sweep.sh: tum
@@ -289,17 +289,38 @@ def main():
     torch.cuda.synchronize(dev)
     status = (bufs[0]["statusM"] if merged else
               torch.stack([b["status"] for b in bufs] + ([bufs[0]["statusR"]] if stereo else []))).cpu().numpy()
-    if status.any():
-        raise SystemExit(f"extraction reported status {status.tolist()}")
     counts = (bufs[0]["countsM"] if merged else bufs[0]["counts"][1:]).cpu().numpy()
     n_kp = float(counts.mean())
+    # every rank's extraction status and mean keypoint count go to every rank: a failing rank makes ALL ranks exit non-zero
+    # together (a lone SystemExit would leave its peers blocked in the next barrier until the driver's timeout), and rank 0
+    # prints what each device produced, so that a slow or failing device can be told from a slow collective
+    mdev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")   # the few-byte bookkeeping exchanges
+    mine = torch.tensor([float(status.max()), n_kp], dtype=torch.float64, device=mdev)
+    per_rank = [mine.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
+    per_rank_status = [int(t[0].item()) for t in per_rank]
+    per_rank_keypoints = [round(float(t[1].item()), 1) for t in per_rank]
+    if any(per_rank_status):
+        if rank == 0:
+            print(json.dumps({"error": "extraction reported a non-zero status", "per_rank_status": per_rank_status,
+                              "per_rank_keypoints": per_rank_keypoints}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(3)
     handles = exs + ([exR] if exR is not None else [])
 
     # calibration pass: which kernel dominates?  (all kernels timed with HIP events on the launch stream)
     for e in handles:
         e.profile_enable(0x1ff)
+    torch.cuda.synchronize(dev)
+    tc = time.perf_counter()
     for _ in range(2 * NS):
         step()
+    if gatherer is not None:
+        gatherer.wait_all()
+    torch.cuda.synchronize(dev)
+    calib_ms = (time.perf_counter() - tc) / (2 * NS) * 1e3
     prof = {}
     for e in handles:
         for kname, (ms, n) in e.profile_read(reset=True).items():
@@ -320,13 +341,35 @@ def main():
     if gatherer is not None:
         gatherer.wait_all()
     torch.cuda.synchronize(dev)
+    dt_own = time.perf_counter() - t0      # this rank's own K steps (its records handed over), before it waits for the others
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    own = torch.tensor([dt_own], dtype=torch.float64, device=mdev)
+    per_rank_dt = [own.clone() for _ in range(world)]
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank_dt, own)
     dt = float(tmax.item())
+    per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 4) for t in per_rank_dt]
+    # the exchange alone (events around the synchronous collective on the buffers of the last step), MAX over ranks: what a
+    # step would cost if nothing but the gather of its records ran -- with the per-rank times above it attributes a
+    # sub-linear scaling curve to the collective, to rank 0's ingress, or to one slow device
+    gather_ms = None
+    if gatherer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gatherer.collective_only()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        e0.record()
+        for _ in range(4):
+            gatherer.collective_only()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        g = torch.tensor([e0.elapsed_time(e1) / 4], dtype=torch.float64, device=dev)
+        dist.all_reduce(g, op=dist.ReduceOp.MAX)
+        gather_ms = round(float(g.item()), 4)
     dom_ms, dom_launches = 0.0, 0
     for e in handles:
         ms_, n_ = e.profile_read(reset=True)[dominant]
@@ -346,13 +389,28 @@ def main():
         total_fused = sum(fused.values()) * imgs_per_unit
         traffic = committed_counters("traffic", args.config, B, W, H, NF)
         sq = committed_counters("sq", args.config, B, W, H, NF)
-        issue_frac = None
+        # per-port busy fractions of the dominant kernel over its LIVE launch duration, at the clock the chip held during that
+        # kernel (GRBM_GUI_ACTIVE / 8 / duration of the counter pass).  The ports issue independently (a vector, a scalar and an
+        # LDS instruction of different waves can leave a SIMD / CU in the same cycle), so the fractions do not add:
+        #   valu = SQ_INSTS_VALU x issue cycles per instruction of the kernel's rate-class mix (static, tools/valu_mix.py:
+        #          2 full-rate, 3 shifts, 4 half-rate classes) / (1024 SIMDs x cycles)
+        #   salu = SQ_INSTS_SALU / (256 CUs x cycles)      (one scalar instruction per cycle per CU)
+        #   lds  = SQ_LDS_IDX_ACTIVE / (256 CUs x cycles)  (LDS-array cycles, bank conflicts included)
+        ports = None
         if sq is not None and dominant in sq["kernels"] and avg_launch_s > 0:
-            # wave-instructions of the three in-order issue classes over the slots a SIMD offers at the full VALU cadence
-            # (one wave64 instruction per 2 cycles per SIMD-32, at the 2.4 GHz peak clock, over the LIVE launch duration)
             ks = sq["kernels"][dominant]
-            insts = ks["SQ_INSTS_VALU"] + ks["SQ_INSTS_SALU"] + ks["SQ_INSTS_LDS"]
-            issue_frac = round(insts / (avg_launch_s * SCLK_PEAK_HZ / 2 * N_SIMD), 4)
+            clk = ks.get("clock_ghz")
+            cyc = avg_launch_s * (clk if clk else SCLK_PEAK_HZ / 1e9) * 1e9
+            cpv = ks.get("valu_mix_static", {}).get("cycles_per_valu")
+            ports = {"clock_ghz": clk, "clock_source": "GRBM_GUI_ACTIVE/8/duration (PMC pass)" if clk else "peak clock assumed",
+                     "valu_frac": round(ks["SQ_INSTS_VALU"] * cpv / (N_SIMD * cyc), 4) if cpv else None,
+                     "valu_cycles_per_inst_static": cpv,
+                     "valu_frac_if_all_full_rate": round(ks["SQ_INSTS_VALU"] * 2 / (N_SIMD * cyc), 4),
+                     "salu_frac": round(ks["SQ_INSTS_SALU"] / (N_SIMD / 4 * cyc), 4),
+                     "lds_frac": round(ks["SQ_LDS_IDX_ACTIVE"] / (N_SIMD / 4 * cyc), 4) if "SQ_LDS_IDX_ACTIVE" in ks else None,
+                     "lds_bank_conflict_share": round(ks["SQ_LDS_BANK_CONFLICT"] / ks["SQ_LDS_IDX_ACTIVE"], 4) if ks.get("SQ_LDS_IDX_ACTIVE") else None,
+                     "valu_lane_inst_per_pixel": round(ks["SQ_INSTS_VALU"] * 64 / (model[dominant] * B * imgs_per_unit / max(launches_per_step, 1e-9)), 2)
+                                                 if dominant == "k_fast_rows" else None}
         metric = {"tum": "frames/sec ORB extract+match (1000 kp, 640x480)"}.get(
             args.config if (W, H, NF) == (640, 480, 1000) else "", f"frames/sec ORB extract+match ({NF} kp, {W}x{H}{', stereo' if stereo else ''})")
         kind = (f"synthetic {W}x{H} stereo stream (stereo frame = left + right image, both extracted), nFeatures={NF}, 8 levels, "
@@ -372,7 +430,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": int(traffic["kernels"][dominant]["hbm_bytes_per_launch"]) if traffic and dominant in traffic["kernels"] else None,
-                         "issue_frac": issue_frac,
+                         "ports": ports,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_us": round(avg_launch_s * 1e6, 2),
                          # SURVEY 8(d) model (unfused pipeline: includes 2P for a blurred image that is never written here) ...
@@ -381,10 +439,18 @@ def main():
                          # ... and the bytes the fused kernels really have to move
                          "end_to_end_fused_GBs": round(total_fused * fps / world / 1e9, 2),
                          "end_to_end_fused_frac": round(total_fused * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
+            # HIP events of the CALIBRATION pass (every kernel slot timed, 2 steps per pipeline), which runs slower than the timed
+            # region (one slot timed): its own wall time per step is printed beside the sum so that the two can be compared
             "kernel_ms_per_step": {k: round(v[0] / 2, 4) for k, v in prof.items()},
+            "kernel_ms_sum": round(sum(v[0] / 2 for v in prof.values()), 4),
+            "calibration_ms_per_step": round(calib_ms, 4),
             # with several pipelines, or the forked launch sequence, per-kernel durations include time shared with other kernels
             "kernel_ms_overlapped": NS > 1 or int(os.environ.get("ORBX_FORK_LEVEL", "0")) > 0 or (stereo and args.stereo_streams == 2),
         }
+        if world > 1:
+            out.update({"per_rank_status": per_rank_status, "per_rank_keypoints": per_rank_keypoints,
+                        "per_rank_ms_per_step": per_rank_ms, "gather_ms_per_step": gather_ms,
+                        "gather_bytes_per_rank_per_step": int(B * sharding.record_bytes(cap))})
         if not stereo and prof["k_match"][0] > 0 and os.environ.get("ORBX_MATCH_KERNEL") != "valu":
             # the one GEMM-shaped kernel of the path: brute-force Hamming as v_mfma_i32_32x32x32_i8 (dist = |q| + |t| - 2 q.t);
             # 2 operations per (query bit, train bit) pair against the dense int8 peak (2 x the 2.5 PFLOP/s bf16 peak).

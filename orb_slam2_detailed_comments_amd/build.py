@@ -19,11 +19,12 @@ HEADERS = ["orbx_device.h", "orbx_internal.h", "orbx_launch.h", "orbx_sincos.h",
 
 
 def kernels_hash():
-    """identity of the device code (kernel source + device header): profiles/*_traffic.json and *_sq.json carry it, so counters
-    taken on other kernels read as 'not measured' in bench.py instead of as stale numbers"""
+    """identity of the device code AND of what decides its launch geometry (kernel source, device header, the launch plans in
+    orbx_api.cpp / orbx_launch.h / orbx_internal.h): profiles/*_traffic.json and *_sq.json carry it, so counters taken on other
+    kernels or other launch plans read as 'not measured' in bench.py instead of as stale numbers"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("orbx_kernels.hip", "orbx_device.h"):
+    for f in ("orbx_kernels.hip", "orbx_device.h", "orbx_api.cpp", "orbx_launch.h", "orbx_internal.h"):
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -95,17 +95,25 @@ class RecordGatherer:
             self.work[s].wait()
             self.work[s] = None
         pack_records(counts, kps, desc, out=self.send[s])
-        if self.world == 1:
-            self.recv[s].copy_(self.send[s])
-            w = None
-        elif self.mode == "all_gather":
-            w = dist.all_gather_into_tensor(self.recv[s], self.send[s], group=self.group, async_op=async_op)
-        else:
-            parts = list(self.recv[s].view(self.world, self.frames_per_rank, self.rb).unbind(0)) if self.rank == self.root else None
-            w = dist.gather(self.send[s], parts, dst=self.root, group=self.group, async_op=async_op)
+        w = self._collective(s, async_op)
         self.work[s] = w if async_op else None
         self.slot ^= 1
         return self.recv[s]
+
+    def _collective(self, s, async_op):
+        if self.world == 1:
+            self.recv[s].copy_(self.send[s])
+            return None
+        if self.mode == "all_gather":
+            return dist.all_gather_into_tensor(self.recv[s], self.send[s], group=self.group, async_op=async_op)
+        parts = list(self.recv[s].view(self.world, self.frames_per_rank, self.rb).unbind(0)) if self.rank == self.root else None
+        return dist.gather(self.send[s], parts, dst=self.root, group=self.group, async_op=async_op)
+
+    def collective_only(self):
+        """the exchange alone, synchronous, on what the send buffer of slot 0 holds (bench.py times it between two events to
+        tell the collective's share of a step from the compute's)"""
+        self.wait_all()
+        self._collective(0, False)
 
     def wait_all(self):
         for i in (0, 1):

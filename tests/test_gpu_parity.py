@@ -383,7 +383,7 @@ def test_bench_line_contract():
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in j
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "u8" and j["value"] > 1000
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "issue_frac")) <= set(j["roofline"])
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "ports")) <= set(j["roofline"])
     assert j["roofline"]["traffic"] is None            # counters are committed for the default batch only: never a stale number
     assert j["roofline_mfma"]["kernel"] == "k_match" and j["roofline_mfma"]["bound"] == "mfma"
 

@@ -99,3 +99,25 @@ def test_two_ranks_sharing_gpu0_equal_one_process():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)], res
+
+
+def test_bench_two_rank_line_carries_per_rank_fields():
+    """the N > 1 path of bench.py, rehearsed with two ranks sharing GPU 0 (gloo; the 8-GPU run is the driver's): ONE json line from
+    rank 0 with every rank's status / keypoint count / own step time and the collective's own time, so that the first scaling
+    curve the driver takes can be attributed"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ORBX_BENCH_SHARE_GPU0="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--batch", "8",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, p.stdout[-2000:]
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["frames_per_gpu_per_step"] == 8
+    assert j["per_rank_status"] == [0, 0] and len(j["per_rank_keypoints"]) == 2 and min(j["per_rank_keypoints"]) > 500
+    assert len(j["per_rank_ms_per_step"]) == 2 and all(0 < t <= j["ms_per_step"] * 1.001 for t in j["per_rank_ms_per_step"])
+    assert j["gather_ms_per_step"] > 0 and j["gather_bytes_per_rank_per_step"] > 8 * 1000 * 60
+    assert j["value"] == pytest.approx(2 * 8 * 2 / (j["ms_per_step"] * 2 / 1e3), rel=1e-2)
