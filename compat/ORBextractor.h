@@ -91,7 +91,7 @@ public:
 
     std::vector<cv::Mat> mvImagePyramid;
 
-    orbx_handle *handle() { return h_; }   // for compat/Frame_stereo.inl and ORBmatcher_gpu.h
+    orbx_handle *handle() { return h_; }   // for compat/Frame_stereo.inl and compat/ORBmatcher.h
 
 protected:
     orbx_handle *h_ = nullptr;

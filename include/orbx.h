@@ -144,7 +144,8 @@ orbx_status orbx_hamming_matrix(orbx_handle *h, const uint8_t *q, int nq, const 
 
 /* ---- matcher policies on the path ------------------------- */
 /* Frame::AssignFeaturesToGrid + PosInGrid (src/Frame.cc:432-460, 729-745): 64 x 48 buckets over keypoints that the
- * caller keeps alive; bounds = mnMinX, mnMaxX, mnMinY, mnMaxY.  Host-side (the reference keeps it host-side too). */
+ * caller keeps alive; bounds = mnMinX, mnMaxX, mnMinY, mnMaxY.  Host-side utility (the reference's own form); every policy
+ * entry point below builds and queries the grid ON THE DEVICE instead (orbx_grid_build_device / orbx_gated_candidates). */
 typedef struct orbx_grid orbx_grid;
 orbx_grid *orbx_grid_create(const orbx_keypoint *kps, int n, float min_x, float max_x, float min_y, float max_y);
 void orbx_grid_destroy(orbx_grid *g);
@@ -347,7 +348,8 @@ orbx_status orbx_bow_vectors(const orbx_vocabulary *voc, const uint32_t *word_id
  * dist = mDistCoef (k1, k2, p1, p2[, k3], at most 14); dist[0] == 0 copies the keypoints unchanged (:772-776).  OpenCV 3.2
  * arithmetic (double precision, five fixed iterations): parity unpinned, like every OpenCV-owned stage.  The device form
  * works on the buffers orbx_extract_batch_device filled (records `cap` apart, counts per frame) so that the keypoints need
- * not leave the GPU; AssignFeaturesToGrid stays orbx_grid_create (host, like the selection passes that read the grid). */
+ * not leave the GPU; AssignFeaturesToGrid on those buffers is orbx_grid_build_device (below), so a gated match reads them
+ * where the extraction left them. */
 orbx_status orbx_undistort_keypoints_device(orbx_handle *h, int nframes, const orbx_keypoint *d_kps, const int32_t *d_counts,
                                             int cap, const float *camera4, const float *dist, int ndist,
                                             orbx_keypoint *d_kps_un);
