@@ -1557,14 +1557,20 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
                         // the smallest split that still fills the chip (every extra split repeats the query expansion and
                         // one partial record per query)
 #define MT_WAVES 4      // waves per block; they share the train key table
-#define MT_QPW 64       // queries per wave: two MFMA column tiles
-#define MT_QPB (MT_WAVES * MT_QPW)
+// Query column tiles (of 32) per wave, QT: the expanded train tile (A operand: 32 shift-and pairs) and its key registers serve QT
+// MFMA chains.  QT = 2: 64 B-operand registers, three waves per SIMD without a spill (round 2 capped the registers for four
+// and spilled 11 of them inside the MFMA loop).  QT = 4: a block walks its train tiles ONCE for 512 queries -- half the train
+// loads, half the expansions and half the key-table reads per distance -- with 128 B-operand + 64 accumulator registers, two
+// waves per SIMD; the launcher takes it when the launch still fills the chip that way.
+#define MT_QPW(QT) (32 * (QT))
+#define MT_QPB(QT) (MT_WAVES * MT_QPW(QT))
 #define MT_CHUNK 4096   // train descriptors per key table (12 index bits in the key)
 typedef int mt_v4i __attribute__((ext_vector_type(4)));
 typedef int mt_v16i __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ uint32_t mt_min2(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t mt_max2(uint32_t a, uint32_t b) { return a > b ? a : b; }
-__global__ __launch_bounds__(64 * MT_WAVES, 4) void k_match(const uint8_t *__restrict__ q, const int *__restrict__ nq,
+template <int QT>
+__global__ __launch_bounds__(64 * MT_WAVES, QT == 2 ? 3 : 2) void k_match(const uint8_t *__restrict__ q, const int *__restrict__ nq,
                                                          long long q_stride, const uint8_t *__restrict__ t,
                                                          const int *__restrict__ nt, long long t_stride,
                                                          uint2 *__restrict__ partial, int *__restrict__ best_idx,
@@ -1573,7 +1579,7 @@ __global__ __launch_bounds__(64 * MT_WAVES, 4) void k_match(const uint8_t *__res
     __shared__ __attribute__((aligned(16))) int s_tk[MT_CHUNK];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pr = blockIdx.z, sp = blockIdx.y;
     const int NQ = min(nq[pr], out_stride), NT = min(nt[pr], 1 << 20);   // contract (orbx.h): counts beyond out_stride are ignored
-    if ((int)blockIdx.x * MT_QPB >= NQ) return;
+    if ((int)blockIdx.x * MT_QPB(QT) >= NQ) return;
     const int r = lane & 31, h = lane >> 5;
     const uint8_t *qp = q + (long long)pr * q_stride;
     const uint8_t *tp = t + (long long)pr * t_stride;
@@ -1581,12 +1587,12 @@ __global__ __launch_bounds__(64 * MT_WAVES, 4) void k_match(const uint8_t *__res
     const int per = ((NT + 31) / 32 + nsplit - 1) / nsplit * 32;
     const int j0 = min(NT, sp * per), j1 = min(NT, j0 + per);
     // ---- queries: lane (r, h) holds bytes 16h .. 16h+15 of query r of each tile, expanded bit plane by bit plane
-    const int qw = blockIdx.x * MT_QPB + w * MT_QPW;
+    const int qw = blockIdx.x * MT_QPB(QT) + w * MT_QPW(QT);
     const bool wave_on = qw < NQ;
-    mt_v4i bq[2][8];
-    int pq[2];
+    mt_v4i bq[QT][8];
+    int pq[QT];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < QT; ++c) {
         const int qi = qw + 32 * c + r;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (qi < NQ) v = *(const uint4 *)(qp + (long long)qi * 32 + 16 * h);
@@ -1601,7 +1607,9 @@ __global__ __launch_bounds__(64 * MT_WAVES, 4) void k_match(const uint8_t *__res
         }
     }
     // running result over the chunks, in the output format dist << 20 | index
-    uint32_t gbest[2] = {0xffffffffu, 0xffffffffu}, gsecond[2] = {0xffffffffu, 0xffffffffu};
+    uint32_t gbest[QT], gsecond[QT];
+#pragma unroll
+    for (int c = 0; c < QT; ++c) gbest[c] = gsecond[c] = 0xffffffffu;
     for (int c0 = j0; c0 < j1; c0 += MT_CHUNK) {
         const int c1 = min(j1, c0 + MT_CHUNK), n = c1 - c0, npad = (n + 31) & ~31;
         __syncthreads();   // the previous chunk's table is no longer read
@@ -1616,7 +1624,9 @@ __global__ __launch_bounds__(64 * MT_WAVES, 4) void k_match(const uint8_t *__res
         }
         __syncthreads();
         if (!wave_on) continue;
-        int best[2] = {0x7fffffff, 0x7fffffff}, second[2] = {0x7fffffff, 0x7fffffff};
+        int best[QT], second[QT];
+#pragma unroll
+        for (int c = 0; c < QT; ++c) best[c] = second[c] = 0x7fffffff;
         const uint8_t *trow = tp + (long long)(c0 + r) * 32 + 16 * h;
         uint4 ta = make_uint4(0, 0, 0, 0);
         if (r < n) ta = *(const uint4 *)trow;
@@ -1625,15 +1635,16 @@ __global__ __launch_bounds__(64 * MT_WAVES, 4) void k_match(const uint8_t *__res
             // next tile's descriptors requested before this tile's MFMAs
             ta = make_uint4(0, 0, 0, 0);
             if (jt + 32 + r < n) ta = *(const uint4 *)(trow + (long long)(jt + 32) * 32);
-            mt_v16i acc0, acc1;
+            mt_v16i acc[QT];
             {
                 const int4 *kp = (const int4 *)(s_tk + jt + 4 * h);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int4 k4 = kp[2 * g];   // rows 8g + 4h .. + 3 of the tile = registers 4g .. 4g+3
-                    acc0[4 * g] = k4.x; acc0[4 * g + 1] = k4.y; acc0[4 * g + 2] = k4.z; acc0[4 * g + 3] = k4.w;
+                    acc[0][4 * g] = k4.x; acc[0][4 * g + 1] = k4.y; acc[0][4 * g + 2] = k4.z; acc[0][4 * g + 3] = k4.w;
                 }
-                acc1 = acc0;
+#pragma unroll
+                for (int c = 1; c < QT; ++c) acc[c] = acc[0];
             }
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
@@ -1648,22 +1659,23 @@ __global__ __launch_bounds__(64 * MT_WAVES, 4) void k_match(const uint8_t *__res
                     a[0] = (int)((tc.x >> 1) & 0x40404040u); a[1] = (int)((tc.y >> 1) & 0x40404040u);
                     a[2] = (int)((tc.z >> 1) & 0x40404040u); a[3] = (int)((tc.w >> 1) & 0x40404040u);
                 }
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][p], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][p], acc1, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < QT; ++c) acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[c][p], acc[c], 0, 0, 0);
             }
             // best <= second always: the new second-smallest is the median of (best, second, key)  (one v_med3_i32)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int k0 = acc0[i], k1 = acc1[i];
-                second[0] = max(min(best[0], second[0]), min(max(best[0], second[0]), k0));
-                best[0] = min(best[0], k0);
-                second[1] = max(min(best[1], second[1]), min(max(best[1], second[1]), k1));
-                best[1] = min(best[1], k1);
+#pragma unroll
+                for (int c = 0; c < QT; ++c) {
+                    const int kc = acc[c][i];
+                    second[c] = max(min(best[c], second[c]), min(max(best[c], second[c]), kc));
+                    best[c] = min(best[c], kc);
+                }
             }
         }
         // fold the chunk into the running result
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < QT; ++c) {
             const uint32_t b = best[c] == 0x7fffffff ? 0xffffffffu
                                                      : ((uint32_t)((best[c] >> 12) + pq[c] - 256) << 20) | (uint32_t)(c0 + (best[c] & 4095));
             const uint32_t s2 = second[c] == 0x7fffffff ? 0xffffffffu
@@ -1675,7 +1687,7 @@ __global__ __launch_bounds__(64 * MT_WAVES, 4) void k_match(const uint8_t *__res
     if (!wave_on) return;
     // the two lane halves hold different train rows of the same query
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < QT; ++c) {
         const uint32_t ob = (uint32_t)__shfl_xor((int)gbest[c], 32), os = (uint32_t)__shfl_xor((int)gsecond[c], 32);
         const uint32_t second = mt_min2(mt_min2(gsecond[c], os), mt_max2(gbest[c], ob));
         const uint32_t best = mt_min2(gbest[c], ob);
@@ -2517,10 +2529,9 @@ void orbx_launch_block_dist(hipStream_t s, const uint8_t *d1, const uint8_t *d2,
 size_t orbx_match_workspace_bytes(int npairs, int out_stride) { return (size_t)npairs * MT_SPLIT * out_stride * sizeof(uint2); }
 void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,
                        const uint8_t *t, const int *nt, long long t_stride, int *best_idx, int *best_dist,
-                       int *second_dist, int out_stride, void *workspace) {
+                       int *second_dist, int out_stride, void *workspace, bool use_valu) {
     if (npairs <= 0 || max_nq <= 0) return;
-    const char *kind = getenv("ORBX_MATCH_KERNEL");   // read per launch: the parity tests run both kernels in one process
-    if (kind && !strcmp(kind, "valu")) {
+    if (use_valu) {   // the vector-pipe kernel (orbx_params-free A/B switch ORBX_MATCH_KERNEL=valu, read once per handle)
         const int qblocks = (max_nq + 127) / 128;
         const long long base = (long long)qblocks * npairs;
         const int nsplit = (int)std::min<long long>(MT_SPLIT, std::max<long long>(1, (16384 + base - 1) / base));
@@ -2530,13 +2541,18 @@ void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, 
                            best_idx, best_dist, second_dist, out_stride, nsplit);
         return;
     }
-    // target waves per launch (the chip holds 4096 waves of this kernel at once), then the split that reaches it
-    static int target = -1;
-    if (target < 0) { const char *e = getenv("ORBX_MATCH_WAVES"); target = e ? atoi(e) : 4096; }
-    const int qblocks = (max_nq + MT_QPB - 1) / MT_QPB;
-    const long long base = (long long)((max_nq + MT_QPW - 1) / MT_QPW) * npairs;
-    const int nsplit = (int)std::min<long long>(MT_SPLIT, std::max<long long>(1, target / base));
-    hipLaunchKernelGGL(k_match, dim3(qblocks, nsplit, npairs), dim3(64 * MT_WAVES), 0, s, q, nq,
+    // 512 queries per block (QT = 4, two waves per SIMD: the chip holds 2048 such waves) when the launch fills the chip that
+    // way without splitting the train set; otherwise 256 per block and the train split that reaches ~4096 waves
+    const long long waves4 = (long long)((max_nq + MT_QPW(4) - 1) / MT_QPW(4)) * npairs;
+    if (waves4 >= 2048) {
+        hipLaunchKernelGGL(k_match<4>, dim3((max_nq + MT_QPB(4) - 1) / MT_QPB(4), 1, npairs), dim3(64 * MT_WAVES), 0, s, q, nq,
+                           q_stride, t, nt, t_stride, (uint2 *)workspace, best_idx, best_dist, second_dist, out_stride, 1);
+        return;
+    }
+    const int qblocks = (max_nq + MT_QPB(2) - 1) / MT_QPB(2);
+    const long long base = (long long)((max_nq + MT_QPW(2) - 1) / MT_QPW(2)) * npairs;
+    const int nsplit = (int)std::min<long long>(MT_SPLIT, std::max<long long>(1, 4096 / base));
+    hipLaunchKernelGGL(k_match<2>, dim3(qblocks, nsplit, npairs), dim3(64 * MT_WAVES), 0, s, q, nq,
                        q_stride, t, nt, t_stride, (uint2 *)workspace, best_idx, best_dist, second_dist, out_stride, nsplit);
     if (nsplit > 1)
         hipLaunchKernelGGL(k_match_merge, dim3((max_nq + 255) / 256, npairs), dim3(256), 0, s, nq, (const uint2 *)workspace,
