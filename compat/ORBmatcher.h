@@ -299,6 +299,94 @@ public:
         return n;
     }
 
+    // ---- the loop around the call above, as ONE device round trip: LocalMapping::SearchInNeighbors (src/LocalMapping.cc:750-768)
+    //        for (pKFi : vpTargetKFs) matcher.Fuse(pKFi, vpMapPointMatches);      ->      matcher.FuseBatch(vpTargetKFs, vpMapPointMatches);
+    // (10-20 neighbour keyframes + their second neighbours: every synchronous orbx_fuse call pays ~60 us of upload / launch /
+    // download before it has done any work; orbx_fuse_batch pays it once.)  Same map as the loop, step for step: the selection of
+    // a keyframe depends on earlier iterations only through (a) pMP->isBad() / IsInKeyFrame(pKF), tested again here at the moment
+    // the reference would test them (:1118-1121), and (b) the descriptor of a point that survived `pMPinKF->Replace(pMP)` --
+    // MapPoint::Replace ends in ComputeDistinctiveDescriptors() -- so points whose 32 bytes changed are re-submitted (alone,
+    // orbx_fuse) for the keyframes still to come.
+    int FuseBatch(const std::vector<KeyFrame *> &vpTargetKFs, const std::vector<MapPoint *> &vpMapPoints, const float th = 3.0) {
+        const int K = (int)vpTargetKFs.size(), N = (int)vpMapPoints.size();
+        if (K == 0 || N == 0) return 0;
+        std::vector<Points> pts;
+        std::vector<std::vector<int32_t> > best((size_t)K, std::vector<int32_t>((size_t)N, -1));
+        std::vector<orbx_target_view> tv((size_t)K);
+        std::vector<orbx_projected_points> pv((size_t)K);
+        std::vector<const orbx_target_view *> tp((size_t)K);
+        std::vector<const orbx_projected_points *> pp((size_t)K);
+        std::vector<int32_t *> bp((size_t)K);
+        std::vector<int> nf((size_t)K, 0);
+        pts.reserve((size_t)K);
+        for (int k = 0; k < K; ++k) {
+            KeyFrame *pKF = vpTargetKFs[k];
+            const cv::Mat Rcw = pKF->GetRotation(), tcw = pKF->GetTranslation(), Ow = pKF->GetCameraCenter();
+            pts.push_back(Points(N));
+            for (int i = 0; i < N; ++i) {
+                MapPoint *p = vpMapPoints[i];
+                if (!p || p->isBad() || p->IsInKeyFrame(pKF)) continue;
+                float u, v, invz, d;
+                if (!ProjectInto(pKF, p, Rcw, tcw, Ow, u, v, invz, d, true)) continue;
+                pts[k].Set(i, u, v, u - pKF->mbf * invz, p->PredictScale(d, pKF), p->GetDescriptor(), 0.f);
+            }
+        }
+        // one descriptor block for all keyframes (the same MapPoints are projected into each): orbx_fuse_batch uploads it once
+        std::vector<uint8_t> all_desc((size_t)N * 32, 0);
+        for (int i = 0; i < N; ++i)
+            if (vpMapPoints[i] && !vpMapPoints[i]->isBad()) CopyDescriptor(vpMapPoints[i]->GetDescriptor(), &all_desc[(size_t)i * 32]);
+        for (int k = 0; k < K; ++k) {   // (views after the vector stopped growing: they point into it)
+            tv[k] = TargetView(vpTargetKFs[k]); pv[k] = pts[k].View(); pv[k].desc = all_desc.data();
+            tp[k] = &tv[k]; pp[k] = &pv[k]; bp[k] = best[k].data();
+        }
+        Check(orbx_fuse_batch(Handle(), K, tp.data(), pp.data(), th, bp.data(), nf.data()));
+        std::vector<uint8_t> dirty((size_t)N, 0);   // descriptor changed since the batch was computed
+        bool any_dirty = false;
+        int total = 0;
+        for (int k = 0; k < K; ++k) {
+            KeyFrame *pKF = vpTargetKFs[k];
+            if (any_dirty) {   // (b): this keyframe's answers for the points whose descriptor changed, from their new descriptor
+                Points sub(N);
+                bool some = false;
+                for (int i = 0; i < N; ++i) {
+                    if (!dirty[i] || !pts[k].valid[i]) continue;
+                    sub.Set(i, pts[k].uv[2 * i], pts[k].uv[2 * i + 1], pts[k].ur[i], pts[k].level[i], vpMapPoints[i]->GetDescriptor(), 0.f);
+                    some = true;
+                }
+                if (some) {
+                    std::vector<int32_t> b2((size_t)N, -1);
+                    orbx_projected_points sv = sub.View();
+                    int n2 = 0;
+                    Check(orbx_fuse(Handle(), &tv[k], &sv, th, b2.data(), &n2));
+                    for (int i = 0; i < N; ++i) if (sub.valid[i]) best[k][i] = b2[i];
+                }
+            }
+            for (int i = 0; i < N; ++i) {              // the map update of :1248-1275, in point order
+                if (best[k][i] < 0) continue;
+                MapPoint *p = vpMapPoints[i];
+                if (p->isBad() || p->IsInKeyFrame(pKF)) continue;   // (a): what an earlier keyframe's fusion did to this point
+                MapPoint *inKF = pKF->GetMapPoint(best[k][i]);
+                if (inKF) {
+                    if (!inKF->isBad()) {
+                        if (inKF->Observations() > p->Observations()) p->Replace(inKF);
+                        else {
+                            uint8_t before[32], after[32];
+                            CopyDescriptor(p->GetDescriptor(), before);
+                            inKF->Replace(p);
+                            CopyDescriptor(p->GetDescriptor(), after);
+                            for (int b = 0; b < 32; ++b) if (before[b] != after[b]) { dirty[i] = 1; any_dirty = true; break; }
+                        }
+                    }
+                } else {
+                    p->AddObservation(pKF, best[k][i]);
+                    pKF->AddMapPoint(p, best[k][i]);
+                }
+                ++total;
+            }
+        }
+        return total;
+    }
+
     // ---- include/ORBmatcher.h:209 -- src/ORBmatcher.cc:1282-1430, caller LoopClosing::SearchAndFuse (src/LoopClosing.cc:986-1004)
     int Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th, std::vector<MapPoint *> &vpReplacePoint) {
         cv::Mat Rcw, tcw, Ow;

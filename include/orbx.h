@@ -277,6 +277,8 @@ typedef struct orbx_projected_points {
     const uint8_t *desc;      /* pMP->GetDescriptor(), 32 bytes per point */
     const float *angle;       /* pKF->mvKeysUn[i].angle (orbx_search_by_projection_keyframe with check_orientation) */
 } orbx_projected_points;
+/* Every projection-guided entry point below gates its candidates on the device with 16-bit feature indices: a target with more
+ * than 65535 features returns ORBX_UNSUPPORTED (ORB-SLAM2 frames carry 1000-4000). */
 typedef struct orbx_target_view {   /* the KeyFrame / Frame whose features are searched */
     const orbx_keypoint *keys_un;    /* mvKeysUn */
     const uint8_t *desc;             /* mDescriptors */
@@ -294,6 +296,16 @@ orbx_status orbx_fuse(orbx_handle *h, const orbx_target_view *kf, const orbx_pro
 /* ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint) (:1282-1430), lines :1345-1400 */
 orbx_status orbx_fuse_sim3(orbx_handle *h, const orbx_target_view *kf, const orbx_projected_points *pts, float th,
                            int32_t *best_idx, int *nfused);
+/* Batched forms: nproblems (target, point set) pairs through ONE upload, ONE grid-build + gate launch pair and ONE download
+ * instead of a ~60 us synchronous round trip each.  The reference calls Fuse once per neighbour keyframe in a loop --
+ * LocalMapping::SearchInNeighbors (src/LocalMapping.cc:750-768), LoopClosing::SearchAndFuse -- and that loop is the batch.
+ * best_idx[k][i], nfused[k] are exactly what orbx_fuse / orbx_fuse_sim3 return for (kfs[k], pts[k]); all targets must share the
+ * image bounds (min_x .. max_y: Frame's static mnMinX .. mnMaxY).  Earlier iterations of the reference's loop reach later ones
+ * only through pMP->isBad() / IsInKeyFrame(), which the caller re-checks while it applies the results in order. */
+orbx_status orbx_fuse_batch(orbx_handle *h, int nproblems, const orbx_target_view *const *kfs,
+                            const orbx_projected_points *const *pts, float th, int32_t *const *best_idx, int *nfused);
+orbx_status orbx_fuse_sim3_batch(orbx_handle *h, int nproblems, const orbx_target_view *const *kfs,
+                                 const orbx_projected_points *const *pts, float th, int32_t *const *best_idx, int *nfused);
 /* ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, vpPoints, vpMatched, int th) (:415-560), lines :498-556.
  * matched[idx] = vpMatched[idx] != NULL, updated exactly as the reference updates vpMatched (point order matters);
  * best_idx[i] = feature that received point i, -1 = none. */

@@ -875,21 +875,29 @@ static orbx_status pin_reserve(orbx_handle *h, size_t bytes) {
 // One call = one upload (everything packed into page-locked staging), two kernels (k_grid_build, k_gate) and one download that
 // is waited for: the (offset, count) spans, the fill count, and speculatively as many candidate entries as the last call
 // produced (+50 %) -- only a call that produces more than that pays a second copy.
-orbx_status orbx_gate_lists(orbx_handle *h, const orbx_keypoint *tkeys, const uint8_t *tdesc, int nt, float min_x, float max_x,
-                            float min_y, float max_y, const DGateQuery *q, const uint8_t *qdesc, int nq, OrbxGateLists &out) {
+// BATCHED: K targets (keyframes) share the call -- their keypoints / descriptors are packed `fstride` records apart, k_grid_build
+// builds the K grids in one launch (one workgroup per target), every query names its target (DGateQuery::frame) and k_gate
+// serves all of them in one launch.  The ~60 us floor of a synchronous call (upload, two launches, waited download) is paid once
+// per batch instead of once per (keyframe, point set) pair.  All targets share the image bounds (Frame's static mnMinX .. mnMaxY).
+orbx_status orbx_gate_lists_batch(orbx_handle *h, const OrbxGateTarget *tg, int K, float min_x, float max_x, float min_y, float max_y,
+                                  const DGateQuery *q, const uint8_t *qdesc, int nq, OrbxGateLists &out, int nqdesc) {
+    if (nqdesc < 0) nqdesc = nq;
     out.span.assign((size_t)std::max(nq, 0), make_uint2(0u, 0u));
     out.items.clear();
     if (!h || h->host_only) return fail(h ? ORBX_NO_DEVICE : ORBX_BAD_ARGUMENT, "no device handle");
-    if (nq <= 0 || nt <= 0) return ORBX_OK;
-    if (nt > 65535) return fail(ORBX_UNSUPPORTED, "more than 65535 target features");
+    int fstride = 0;
+    for (int k = 0; k < K; ++k) fstride = std::max(fstride, tg[k].n);
+    if (nq <= 0 || K <= 0 || fstride <= 0) return ORBX_OK;
+    if (fstride > 65535) return fail(ORBX_UNSUPPORTED, "more than 65535 target features (candidate entries carry 16-bit indices)");
     DGrid gp;
     if (!grid_params(min_x, max_x, min_y, max_y, gp)) return fail(ORBX_BAD_ARGUMENT, "bad image bounds");
     HIPCHK(hipSetDevice(h->dev));
-    // input block (uploaded in one copy): cursor | keys | descriptors | queries | query descriptors
-    const size_t o_cur = 0, o_keys = 256, o_desc = o_keys + pad256((size_t)nt * sizeof(orbx_keypoint)), o_q = o_desc + pad256((size_t)nt * 32),
-                 o_qd = o_q + pad256((size_t)nq * sizeof(DGateQuery)), in_bytes = o_qd + pad256((size_t)nq * 32);
+    const size_t nrec = (size_t)K * fstride;
+    // input block (uploaded in one copy): cursor | counts | keys | descriptors | queries | query descriptors
+    const size_t o_cur = 0, o_cnt = 256, o_keys = o_cnt + pad256((size_t)K * sizeof(int)), o_desc = o_keys + pad256(nrec * sizeof(orbx_keypoint)),
+                 o_q = o_desc + pad256(nrec * 32), o_qd = o_q + pad256((size_t)nq * sizeof(DGateQuery)), in_bytes = o_qd + pad256((size_t)nqdesc * 32);
     // device-only: bucket offsets | bucket items | spans
-    const size_t o_cb = in_bytes, o_it = o_cb + pad256((size_t)(64 * 48 + 1) * sizeof(int)), o_span = o_it + pad256((size_t)nt * sizeof(uint16_t)),
+    const size_t o_cb = in_bytes, o_it = o_cb + pad256((size_t)K * (64 * 48 + 1) * sizeof(int)), o_span = o_it + pad256(nrec * sizeof(uint16_t)),
                  dev_bytes = o_span + pad256((size_t)nq * sizeof(uint2));
     orbx_status st = scratch_reserve(h, dev_bytes + 256);
     if (st != ORBX_OK) return st;
@@ -901,10 +909,14 @@ orbx_status orbx_gate_lists(orbx_handle *h, const orbx_keypoint *tkeys, const ui
     if (st != ORBX_OK) return st;
     uint8_t *pin_in = h->pin, *pin_out = h->pin + in_bytes;   // pin_out: spans | cursor (256) | items
     memset(pin_in + o_cur, 0, 256);
-    memcpy(pin_in + o_keys, tkeys, (size_t)nt * sizeof(orbx_keypoint));
-    memcpy(pin_in + o_desc, tdesc, (size_t)nt * 32);
+    for (int k = 0; k < K; ++k) {
+        ((int *)(pin_in + o_cnt))[k] = tg[k].n;
+        if (tg[k].n <= 0) continue;
+        memcpy(pin_in + o_keys + (size_t)k * fstride * sizeof(orbx_keypoint), tg[k].keys, (size_t)tg[k].n * sizeof(orbx_keypoint));
+        memcpy(pin_in + o_desc + (size_t)k * fstride * 32, tg[k].desc, (size_t)tg[k].n * 32);
+    }
     memcpy(pin_in + o_q, q, (size_t)nq * sizeof(DGateQuery));
-    memcpy(pin_in + o_qd, qdesc, (size_t)nq * 32);
+    memcpy(pin_in + o_qd, qdesc, (size_t)nqdesc * 32);
     uint8_t *d = scratch_take<uint8_t>(h, dev_bytes);
     uint32_t *dcur = (uint32_t *)(d + o_cur);
     const orbx_keypoint *dk = (const orbx_keypoint *)(d + o_keys);
@@ -913,9 +925,10 @@ orbx_status orbx_gate_lists(orbx_handle *h, const orbx_keypoint *tkeys, const ui
     uint32_t total = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         { ProfScope ps(h, ORBX_K_MATCH);
-          if (attempt == 0) orbx_launch_grid_build(s, gp, 1, dk, nullptr, nt, nt, (int *)(d + o_cb), (uint16_t *)(d + o_it));
+          if (attempt == 0) orbx_launch_grid_build(s, gp, K, dk, (const int *)(d + o_cnt), 0, fstride, (int *)(d + o_cb), (uint16_t *)(d + o_it));
           orbx_launch_gate(s, gp, dk, d + o_desc, (const int *)(d + o_cb), (const uint16_t *)(d + o_it), (const DGateQuery *)(d + o_q),
-                           d + o_qd, nq, (uint2 *)(d + o_span), dcur, h->d_gate_items, (uint32_t)std::min<size_t>(h->gate_items_cap, 0xffffffffu)); }
+                           d + o_qd, nq, (uint2 *)(d + o_span), dcur, h->d_gate_items, (uint32_t)std::min<size_t>(h->gate_items_cap, 0xffffffffu),
+                           fstride); }
         HIPCHK(hipMemcpyAsync(pin_out, d + o_span, span_bytes, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(pin_out + span_bytes, dcur, 4, hipMemcpyDeviceToHost, s));
         if (guess > 0) HIPCHK(hipMemcpyAsync(pin_out + span_bytes + 256, h->d_gate_items, guess * 4, hipMemcpyDeviceToHost, s));
@@ -942,6 +955,11 @@ orbx_status orbx_gate_lists(orbx_handle *h, const orbx_keypoint *tkeys, const ui
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
     return ORBX_OK;
+}
+orbx_status orbx_gate_lists(orbx_handle *h, const orbx_keypoint *tkeys, const uint8_t *tdesc, int nt, float min_x, float max_x,
+                            float min_y, float max_y, const DGateQuery *q, const uint8_t *qdesc, int nq, OrbxGateLists &out) {
+    const OrbxGateTarget tg = {tkeys, tdesc, nt};
+    return orbx_gate_lists_batch(h, &tg, 1, min_x, max_x, min_y, max_y, q, qdesc, nq, out);
 }
 
 // host-buffer form of the primitive itself (tests, tools/policy_rates.py): xyr = (x, y, r) per query, levels = (min, max)

@@ -39,7 +39,10 @@ struct OrbxStereoGeom {
 // Frame grid (64 x 48 buckets over [minx, maxx) x [miny, maxy)): mfGridElementWidthInv / HeightInv of src/Frame.cc:96-99
 struct DGrid { float minx, miny, winv, hinv; };
 // one GetFeaturesInArea query (src/Frame.cc:633-717): centre, radius (negative = query switched off), level band
-struct DGateQuery { float x, y, r; int min_level, max_level; };
+// `frame` = which target of a batched call the query searches (orbx_gate_lists_batch); 0 for the single-target calls
+// `desc` = row of the query-descriptor block this query compares with (-1: its own index; batched calls whose problems share
+// one point set upload the descriptors once)
+struct DGateQuery { float x, y, r; int min_level, max_level; int frame = 0; int desc = -1; };
 // one row of a BoW-guided distance block: descriptor q of set 1 against ncol features of set 2
 struct DDistRow { uint32_t q, col_begin, ncol, out_off; };
 

@@ -19,6 +19,11 @@ struct OrbxGateLists {
     static int dist(uint32_t v) { return (int)(v >> 16); }
 };
 struct orbx_handle;
+struct OrbxGateTarget { const orbx_keypoint *keys; const uint8_t *desc; int n; };   // one target (keyframe / frame) of a batched call
+// K targets sharing the image bounds; q[i].frame names the target query i searches; lists come back per query as below.
+// nqdesc >= 0: qdesc holds nqdesc rows and every query names its row (q[i].desc); -1: one row per query, in query order
+orbx_status orbx_gate_lists_batch(orbx_handle *h, const OrbxGateTarget *tg, int K, float min_x, float max_x, float min_y, float max_y,
+                                  const DGateQuery *q, const uint8_t *qdesc, int nq, OrbxGateLists &out, int nqdesc = -1);
 // target = (keys, desc, nt) with the image bounds of its grid; queries q[nq] (r < 0: switched off) with descriptors qdesc[nq][32]
 orbx_status orbx_gate_lists(orbx_handle *h, const orbx_keypoint *tkeys, const uint8_t *tdesc, int nt, float min_x, float max_x,
                             float min_y, float max_y, const DGateQuery *q, const uint8_t *qdesc, int nq, OrbxGateLists &out);

@@ -2248,11 +2248,17 @@ __global__ __launch_bounds__(256) void k_gate(DGrid gp, const orbx_keypoint *__r
                                               const int *__restrict__ cell_begin, const uint16_t *__restrict__ items,
                                               const DGateQuery *__restrict__ q, const uint8_t *__restrict__ qdesc, int nq,
                                               uint2 *__restrict__ span, uint32_t *__restrict__ cursor,
-                                              uint32_t *__restrict__ out_items, uint32_t cap) {
+                                              uint32_t *__restrict__ out_items, uint32_t cap, int fstride) {
     const int lane = threadIdx.x & 63;
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (qi >= nq) return;
     const DGateQuery Q = q[qi];
+    // batched calls: target Q.frame's keypoints / descriptors / buckets are fstride records further on (item indices stay
+    // relative to their target)
+    kps += (long long)Q.frame * fstride;
+    desc += (long long)Q.frame * fstride * 32;
+    items += (long long)Q.frame * fstride;
+    cell_begin += (long long)Q.frame * (GR_CELLS + 1);
     // GetFeaturesInArea's cell range (:643-668); a negative radius switches the query off
     const int x0 = max(0, (int)floorf((Q.x - gp.minx - Q.r) * gp.winv));
     const int x1 = min(GR_COLS - 1, (int)ceilf((Q.x - gp.minx + Q.r) * gp.winv));
@@ -2277,7 +2283,7 @@ __global__ __launch_bounds__(256) void k_gate(DGrid gp, const orbx_keypoint *__r
     }
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     if (n == 0 || base + (uint32_t)n > cap) return;
-    const uint4 *qp = (const uint4 *)(qdesc + (long long)qi * 32);
+    const uint4 *qp = (const uint4 *)(qdesc + (long long)(Q.desc >= 0 ? Q.desc : qi) * 32);
     const uint4 qa = qp[0], qb = qp[1];
     uint32_t w = base;
     for (int ix = x0; ix <= x1; ++ix) {
@@ -2516,10 +2522,10 @@ void orbx_launch_grid_build(hipStream_t s, const DGrid &gp, int nframes, const o
 }
 void orbx_launch_gate(hipStream_t s, const DGrid &gp, const orbx_keypoint *kps, const uint8_t *desc, const int *cell_begin,
                       const uint16_t *items, const DGateQuery *q, const uint8_t *qdesc, int nq, uint2 *span, uint32_t *cursor,
-                      uint32_t *out_items, uint32_t cap) {
+                      uint32_t *out_items, uint32_t cap, int fstride) {
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_gate, dim3((nq + 3) / 4), dim3(256), 0, s, gp, kps, desc, cell_begin, items, q, qdesc, nq, span, cursor,
-                       out_items, cap);
+                       out_items, cap, fstride);
 }
 void orbx_launch_block_dist(hipStream_t s, const uint8_t *d1, const uint8_t *d2, const DDistRow *rows, const uint32_t *col_idx,
                             int nrows, uint16_t *out) {

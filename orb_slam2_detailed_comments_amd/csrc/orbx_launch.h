@@ -36,7 +36,7 @@ void orbx_launch_grid_build(hipStream_t s, const DGrid &gp, int nframes, const o
                             int cap, int *cell_begin, uint16_t *items);
 void orbx_launch_gate(hipStream_t s, const DGrid &gp, const orbx_keypoint *kps, const uint8_t *desc, const int *cell_begin,
                       const uint16_t *items, const DGateQuery *q, const uint8_t *qdesc, int nq, uint2 *span, uint32_t *cursor,
-                      uint32_t *out_items, uint32_t cap);
+                      uint32_t *out_items, uint32_t cap, int fstride);
 void orbx_launch_block_dist(hipStream_t s, const uint8_t *d1, const uint8_t *d2, const DDistRow *rows, const uint32_t *col_idx,
                             int nrows, uint16_t *out);
 void orbx_launch_hamming_matrix(hipStream_t s, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *dist);

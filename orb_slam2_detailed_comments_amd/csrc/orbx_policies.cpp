@@ -307,21 +307,16 @@ orbx_status point_lists(orbx_handle *h, const orbx_target_view *t, const orbx_pr
     return orbx_gate_lists(h, t->keys_un, t->desc, t->n, t->min_x, t->max_x, t->min_y, t->max_y, gq.data(), p->desc, p->n, gl);
 }
 
+// the reference's selection loops over candidate lists; queries of the problem start at entry q0 of the lists (batched calls)
 // level band [pred - 1, pred], no chi2 gate; `taken` as the reference's vpMatched (NULL = not used)
-orbx_status project_and_pick(orbx_handle *h, const orbx_target_view *t, const orbx_projected_points *p, float th, int init_best,
-                             int max_dist, uint8_t *taken, int32_t *best_idx, int *count) {
-    *count = 0;
-    for (int i = 0; i < p->n; ++i) best_idx[i] = -1;
-    if (p->n == 0 || t->n == 0) return ORBX_OK;
-    OrbxGateLists gl;
-    orbx_status st = point_lists(h, t, p, [&](int i) { return th * t->scale_factors[p->level[i]]; }, [](int, int &, int &) {}, gl);
-    if (st != ORBX_OK) return st;
+void pick_select(const orbx_target_view *t, const orbx_projected_points *p, const OrbxGateLists &gl, int q0, int init_best, int max_dist,
+                 uint8_t *taken, int32_t *best_idx, int *count) {
     int n = 0;
     for (int i = 0; i < p->n; ++i) {
         if (!p->valid[i]) continue;
         const int pred = p->level[i];
-        const int nc = gl.count(i);
-        const uint32_t *cl = gl.list(i);
+        const int nc = gl.count(q0 + i);
+        const uint32_t *cl = gl.list(q0 + i);
         int bestDist = init_best, bestIdx = -1;
         for (int c = 0; c < nc; ++c) {
             const int idx = OrbxGateLists::idx(cl[c]);
@@ -338,30 +333,28 @@ orbx_status project_and_pick(orbx_handle *h, const orbx_target_view *t, const or
         }
     }
     *count = n;
+}
+orbx_status project_and_pick(orbx_handle *h, const orbx_target_view *t, const orbx_projected_points *p, float th, int init_best,
+                             int max_dist, uint8_t *taken, int32_t *best_idx, int *count) {
+    *count = 0;
+    for (int i = 0; i < p->n; ++i) best_idx[i] = -1;
+    if (p->n == 0 || t->n == 0) return ORBX_OK;
+    OrbxGateLists gl;
+    orbx_status st = point_lists(h, t, p, [&](int i) { return th * t->scale_factors[p->level[i]]; }, [](int, int &, int &) {}, gl);
+    if (st != ORBX_OK) return st;
+    pick_select(t, p, gl, 0, init_best, max_dist, taken, best_idx, count);
     return ORBX_OK;
 }
-}  // namespace
-
-extern "C" orbx_status orbx_fuse(orbx_handle *h, const orbx_target_view *kf, const orbx_projected_points *pts, float th,
-                                 int32_t *best_idx, int *nfused) {
-    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
-    if (!target_ok(kf) || !points_ok(pts) || !best_idx || !nfused || !kf->inv_level_sigma2 || (kf->n > 0 && !kf->u_right) ||
-        (pts->n > 0 && !pts->u_right))
-        return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
-    *nfused = 0;
-    for (int i = 0; i < pts->n; ++i) best_idx[i] = -1;
-    if (pts->n == 0 || kf->n == 0) return ORBX_OK;
-    const bool fma_mode = orbx_handle_fp_mode(h) == ORBX_FP_GCC_FMA;
-    OrbxGateLists gl;
-    orbx_status st = point_lists(h, kf, pts, [&](int i) { return th * kf->scale_factors[pts->level[i]]; }, [](int, int &, int &) {}, gl);
-    if (st != ORBX_OK) return st;
+// ORBmatcher::Fuse(KeyFrame *, vpMapPoints, th), lines :1168-1245 of the reference, over the candidate lists
+void fuse_select(bool fma_mode, const orbx_target_view *kf, const orbx_projected_points *pts, const OrbxGateLists &gl, int q0,
+                 int32_t *best_idx, int *nfused) {
     int n = 0;
     for (int i = 0; i < pts->n; ++i) {
         if (!pts->valid[i]) continue;
         const float u = pts->uv[2 * i], v = pts->uv[2 * i + 1];
         const int pred = pts->level[i];
-        const int nc = gl.count(i);
-        const uint32_t *cl = gl.list(i);
+        const int nc = gl.count(q0 + i);
+        const uint32_t *cl = gl.list(q0 + i);
         int bestDist = 256, bestIdx = -1;
         for (int c = 0; c < nc; ++c) {
             const int idx = OrbxGateLists::idx(cl[c]);
@@ -383,6 +376,56 @@ extern "C" orbx_status orbx_fuse(orbx_handle *h, const orbx_target_view *kf, con
         if (bestDist <= TH_LOW_) { best_idx[i] = bestIdx; n++; }
     }
     *nfused = n;
+}
+bool fuse_views_ok(const orbx_target_view *kf, const orbx_projected_points *pts) {
+    return target_ok(kf) && points_ok(pts) && kf->inv_level_sigma2 && !(kf->n > 0 && !kf->u_right) && !(pts->n > 0 && !pts->u_right);
+}
+// K (target, point set) problems through ONE upload / grid build / gate launch / download (orbx_gate_lists_batch): the flat
+// query list holds problem k's points at [q0[k], q0[k] + pts[k]->n), window th x scale factor of the predicted level
+orbx_status batch_lists(orbx_handle *h, int K, const orbx_target_view *const *kfs, const orbx_projected_points *const *pts, float th,
+                        std::vector<int> &q0, OrbxGateLists &gl) {
+    std::vector<OrbxGateTarget> tg((size_t)K);
+    q0.assign((size_t)K + 1, 0);
+    for (int k = 0; k < K; ++k) {
+        if (kfs[k]->min_x != kfs[0]->min_x || kfs[k]->max_x != kfs[0]->max_x || kfs[k]->min_y != kfs[0]->min_y || kfs[k]->max_y != kfs[0]->max_y)
+            return orbx_fail(ORBX_BAD_ARGUMENT, "the targets of a batched call must share the image bounds");
+        tg[(size_t)k] = {kfs[k]->keys_un, kfs[k]->desc, kfs[k]->n};
+        q0[(size_t)k + 1] = q0[(size_t)k] + pts[k]->n;
+    }
+    const int nq = q0[(size_t)K];
+    // SearchInNeighbors projects ONE point set into every neighbour: when all problems hand over the same descriptor block it is
+    // uploaded once and every query names its row
+    bool shared = K > 1;
+    for (int k = 1; k < K && shared; ++k) shared = pts[k]->desc == pts[0]->desc && pts[k]->n == pts[0]->n;
+    std::vector<DGateQuery> gq((size_t)nq);
+    std::vector<uint8_t> qd;
+    if (!shared) qd.resize((size_t)nq * 32);
+    for (int k = 0; k < K; ++k) {
+        const orbx_projected_points *p = pts[k];
+        for (int i = 0; i < p->n; ++i) {
+            DGateQuery &g = gq[(size_t)(q0[(size_t)k] + i)];
+            g.x = p->uv[2 * i]; g.y = p->uv[2 * i + 1]; g.r = -1.0f; g.min_level = g.max_level = -1; g.frame = k;
+            g.desc = shared ? i : -1;
+            if (p->valid[i] && kfs[k]->n > 0) g.r = th * kfs[k]->scale_factors[p->level[i]];
+        }
+        if (!shared && p->n > 0) memcpy(qd.data() + (size_t)q0[(size_t)k] * 32, p->desc, (size_t)p->n * 32);
+    }
+    return orbx_gate_lists_batch(h, tg.data(), K, kfs[0]->min_x, kfs[0]->max_x, kfs[0]->min_y, kfs[0]->max_y, gq.data(),
+                                 shared ? pts[0]->desc : qd.data(), nq, gl, shared ? pts[0]->n : -1);
+}
+}  // namespace
+
+extern "C" orbx_status orbx_fuse(orbx_handle *h, const orbx_target_view *kf, const orbx_projected_points *pts, float th,
+                                 int32_t *best_idx, int *nfused) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!fuse_views_ok(kf, pts) || !best_idx || !nfused) return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    *nfused = 0;
+    for (int i = 0; i < pts->n; ++i) best_idx[i] = -1;
+    if (pts->n == 0 || kf->n == 0) return ORBX_OK;
+    OrbxGateLists gl;
+    orbx_status st = point_lists(h, kf, pts, [&](int i) { return th * kf->scale_factors[pts->level[i]]; }, [](int, int &, int &) {}, gl);
+    if (st != ORBX_OK) return st;
+    fuse_select(orbx_handle_fp_mode(h) == ORBX_FP_GCC_FMA, kf, pts, gl, 0, best_idx, nfused);
     return ORBX_OK;
 }
 
@@ -391,6 +434,45 @@ extern "C" orbx_status orbx_fuse_sim3(orbx_handle *h, const orbx_target_view *kf
     if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
     if (!target_ok(kf) || !points_ok(pts) || !best_idx || !nfused) return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
     return project_and_pick(h, kf, pts, th, INT32_MAX, TH_LOW_, nullptr, best_idx, nfused);
+}
+
+// Batched forms.  The reference calls Fuse once per neighbour keyframe in a loop -- LocalMapping::
+// SearchInNeighbors (src/LocalMapping.cc:750-768: every target keyframe against the current keyframe's MapPoints) and
+// LoopClosing::SearchAndFuse (src/LoopClosing.cc: every connected keyframe against the loop MapPoints) -- and a synchronous
+// host-buffer call costs ~60 us before it has done any work.  Here the K problems share one upload, one k_grid_build launch (K
+// grids), one k_gate launch and one download; problem k's outputs are exactly what the single call returns for (kfs[k], pts[k]).
+// What the loop's earlier iterations change in the map (Replace / AddObservation) reaches a later iteration only through
+// pMP->isBad() / IsInKeyFrame(), which the caller re-checks when it applies the results in order (compat/ORBmatcher.h FuseBatch).
+static orbx_status fuse_batch_common(orbx_handle *h, int K, const orbx_target_view *const *kfs, const orbx_projected_points *const *pts,
+                                     float th, int32_t *const *best_idx, int *nfused, bool sim3) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (K < 0 || (K > 0 && (!kfs || !pts || !best_idx || !nfused))) return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    for (int k = 0; k < K; ++k) {
+        if (!kfs[k] || !pts[k] || !(sim3 ? (target_ok(kfs[k]) && points_ok(pts[k])) : fuse_views_ok(kfs[k], pts[k])) || (pts[k]->n > 0 && !best_idx[k]))
+            return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+        nfused[k] = 0;
+        for (int i = 0; i < pts[k]->n; ++i) best_idx[k][i] = -1;
+    }
+    if (K == 0) return ORBX_OK;
+    std::vector<int> q0;
+    OrbxGateLists gl;
+    orbx_status st = batch_lists(h, K, kfs, pts, th, q0, gl);
+    if (st != ORBX_OK) return st;
+    const bool fma_mode = orbx_handle_fp_mode(h) == ORBX_FP_GCC_FMA;
+    for (int k = 0; k < K; ++k) {
+        if (pts[k]->n == 0 || kfs[k]->n == 0) continue;
+        if (sim3) pick_select(kfs[k], pts[k], gl, q0[(size_t)k], INT32_MAX, TH_LOW_, nullptr, best_idx[k], &nfused[k]);
+        else fuse_select(fma_mode, kfs[k], pts[k], gl, q0[(size_t)k], best_idx[k], &nfused[k]);
+    }
+    return ORBX_OK;
+}
+extern "C" orbx_status orbx_fuse_batch(orbx_handle *h, int nproblems, const orbx_target_view *const *kfs,
+                                       const orbx_projected_points *const *pts, float th, int32_t *const *best_idx, int *nfused) {
+    return fuse_batch_common(h, nproblems, kfs, pts, th, best_idx, nfused, false);
+}
+extern "C" orbx_status orbx_fuse_sim3_batch(orbx_handle *h, int nproblems, const orbx_target_view *const *kfs,
+                                            const orbx_projected_points *const *pts, float th, int32_t *const *best_idx, int *nfused) {
+    return fuse_batch_common(h, nproblems, kfs, pts, th, best_idx, nfused, true);
 }
 
 extern "C" orbx_status orbx_search_by_projection_sim3(orbx_handle *h, const orbx_target_view *kf,

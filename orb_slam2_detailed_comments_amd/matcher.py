@@ -210,6 +210,23 @@ class ORBmatcher:
         check(self._L.orbx_fuse(self._ex.handle, C.byref(tv), C.byref(pv), float(th), ptr(out), C.byref(n)))
         return n.value, out[:pv.n].copy()
 
+    def FuseBatch(self, kfs, pts_list, th=3.0, sim3=False):
+        """the loop `for pKFi in vpTargetKFs: matcher.Fuse(pKFi, ...)` of LocalMapping::SearchInNeighbors (src/LocalMapping.cc:750-768)
+        / LoopClosing::SearchAndFuse as ONE call: K (keyframe, projected points) problems through one upload, one grid-build + gate
+        launch pair, one download.  Returns ([nFused_k], [best_idx_k]) -- per problem exactly what Fuse / FuseSim3 return."""
+        import ctypes as C
+        K = len(kfs)
+        assert K == len(pts_list)
+        keep = []
+        tvs = [self._target(kf, keep) for kf in kfs]; pvs = [self._points(p, keep) for p in pts_list]
+        outs = [np.full(max(pv.n, 1), -1, np.int32) for pv in pvs]
+        tarr = (C.c_void_p * max(K, 1))(*[C.addressof(t) for t in tvs]); parr = (C.c_void_p * max(K, 1))(*[C.addressof(p_) for p_ in pvs])
+        oarr = (C.c_void_p * max(K, 1))(*[o.ctypes.data for o in outs])
+        n = (C.c_int * max(K, 1))()
+        fn = self._L.orbx_fuse_sim3_batch if sim3 else self._L.orbx_fuse_batch
+        check(fn(self._ex.handle, K, tarr, parr, C.c_float(th), oarr, n))
+        return [int(n[k]) for k in range(K)], [outs[k][:pvs[k].n].copy() for k in range(K)]
+
     def FuseSim3(self, kf, pts, th):
         """Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint), selection part."""
         import ctypes as C

@@ -17,5 +17,7 @@ int use(Frame &F, Frame &F2, KeyFrame *k1, KeyFrame *k2, std::vector<MapPoint *>
     n += m.SearchBySim3(k1, k2, mps, 1.f, R, t, 7.5f);
     n += m.Fuse(k1, mps, 3.f);
     n += m.Fuse(k1, S, mps, 4.f, mps);
+    std::vector<KeyFrame *> kfs(2, k1);
+    n += m.FuseBatch(kfs, mps, 3.f);
     return n + ORBmatcher::TH_LOW + ORBmatcher::TH_HIGH + ORBmatcher::HISTO_LENGTH;
 }

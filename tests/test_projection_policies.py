@@ -145,6 +145,45 @@ def test_gpu_projection_policies_equal_oracle(fp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fp", [0, 1])
+def test_gpu_fuse_batch_equals_single_calls_and_oracle(fp):
+    """orbx_fuse_batch / orbx_fuse_sim3_batch (the Fuse loops of LocalMapping::SearchInNeighbors, src/LocalMapping.cc:750-768, and
+    LoopClosing::SearchAndFuse as ONE call): per problem the same best_idx / count as the single call and as the oracle; targets
+    of different sizes, an empty target, an empty point set, the same points against several keyframes"""
+    from orb_slam2_detailed_comments_amd import ORBextractor, ORBmatcher, OrbxError, synth
+    frames = synth.stream(640, 480, 4, stream_id=43)
+    ex = ORBextractor(1000, max_batch=4, fp_mode=fp)
+    res = ex.extract_batch(frames)
+    rng = np.random.default_rng(17)
+    sf = ex.GetScaleFactors()
+    mk = lambda k, d: dict(make_target(k, d, rng, 678, 518), scale_factors=sf, inv_level_sigma2=ex.GetInverseScaleSigmaSquares())
+    tg = [mk(k, d) for k, d in res]
+    tg[2] = mk(res[2][0][:300], res[2][1][:300])                       # a smaller keyframe
+    tg.append(mk(res[0][0][:0], res[0][1][:0]))                          # and one without features
+    # SearchInNeighbors: the CURRENT keyframe's points against every neighbour (same point set), plus one other set and an empty one
+    p0, _ = points_from(res[0][0], res[0][1], rng, shift=(-3.0, -2.0))
+    p1, _ = points_from(res[1][0], res[1][1], rng, shift=(-3.0, -2.0))
+    empty = {kk: v[:0] for kk, v in p0.items()}
+    probs = [(tg[1], p0), (tg[2], p0), (tg[3], p0), (tg[2], p1), (tg[4], p0), (tg[1], empty)]
+    m = ORBmatcher(0.7, True, extractor=ex)
+    for sim3, th, single, orc in ((False, 3.0, m.Fuse, lambda t, p: oracle.fuse(t, p, 3.0, fp)),
+                                  (True, 4.0, m.FuseSim3, lambda t, p: oracle.fuse_sim3(t, p, 4.0))):
+        ns, bests = m.FuseBatch([t for t, _ in probs], [p for _, p in probs], th, sim3=sim3)
+        assert len(ns) == len(probs)
+        for k, (t, p) in enumerate(probs):
+            n1, b1 = single(t, p, th)
+            assert ns[k] == n1 and np.array_equal(bests[k], b1), f"problem {k} differs from the single call"
+            if len(t["keys_un"]) and len(p["valid"]):
+                on, ob = orc(t, p)
+                assert ns[k] == on and np.array_equal(bests[k], ob), f"problem {k} differs from the oracle"
+        assert ns[0] > 100 and ns[4] == 0 and ns[5] == 0
+    assert m.FuseBatch([], [], 3.0) == ([], [])
+    other = dict(tg[1], bounds=(0.0, 700.0, 0.0, 518.0))
+    with pytest.raises(OrbxError):
+        m.FuseBatch([tg[1], other], [p0, p0], 3.0)                       # the targets of a batch share the image bounds
+
+
+@pytest.mark.gpu
 def test_gpu_projection_policies_edge_cases():
     from orb_slam2_detailed_comments_amd import ORBextractor, ORBmatcher, OrbxError
     rng = np.random.default_rng(12)

@@ -85,6 +85,24 @@ def main():
     pts, _ = points_from(k1, d1, rng, shift=(-3.0, -2.0))
     add("orbx_fuse", "ORBmatcher.cc:1100-1280 (th 3)", lambda: m.Fuse(t2, pts, 3.0), lambda: oracle.fuse(t2, pts, 3.0, 0))
     add("orbx_fuse_sim3", "ORBmatcher.cc:1282-1430 (th 4)", lambda: m.FuseSim3(t2, pts, 4.0), lambda: oracle.fuse_sim3(t2, pts, 4.0))
+    # the Fuse loops of LocalMapping::SearchInNeighbors / LoopClosing::SearchAndFuse as one batched call: K neighbour keyframes
+    # against the current keyframe's points; us PER PROBLEM next to K single CPU calls
+    # (timed at the C ABI with the views marshalled once -- what compat/ORBmatcher.h's FuseBatch pays; the Python wrapper's
+    # ctypes marshalling of K view structs per call, 10 us per problem, is the test harness's cost, not the library's)
+    import ctypes as C
+    Lc = _capi.lib()
+    for K in (1, 8, 32):
+        keep = []
+        tvs = [m._target(t2, keep) for _ in range(K)]; pvs = [m._points(pts, keep) for _ in range(K)]
+        outs = [np.full(max(pv.n, 1), -1, np.int32) for pv in pvs]
+        tarr = (C.c_void_p * K)(*[C.addressof(t) for t in tvs]); parr = (C.c_void_p * K)(*[C.addressof(p_) for p_ in pvs])
+        oarr = (C.c_void_p * K)(*[o.ctypes.data for o in outs]); nf = (C.c_int * K)()
+        for name, fn, th, orc in (("orbx_fuse_batch", Lc.orbx_fuse_batch, 3.0, lambda: [oracle.fuse(t2, pts, 3.0, 0) for _ in range(K)]),
+                                  ("orbx_fuse_sim3_batch", Lc.orbx_fuse_sim3_batch, 4.0, lambda: [oracle.fuse_sim3(t2, pts, 4.0) for _ in range(K)])):
+            g, c = bench(lambda: _capi.check(fn(ex.handle, K, tarr, parr, C.c_float(th), oarr, nf)), 30), bench(orc, 3)
+            rows.append(dict(entry_point=f"{name} K={K}", reference="LocalMapping.cc:750-768 loop" if "sim3" not in name else "LoopClosing SearchAndFuse loop",
+                             gpu_us=round(g / K, 1), cpu_oracle_us=round(c / K, 1), ratio=round(c / g, 2), problems=K))
+            print(f"{name + f' K={K}':40s} {'us per problem (C ABI)':38s} GPU {g / K:9.1f} us   CPU oracle {c / K:10.1f} us   x{c / g:6.2f}", flush=True)
     matched = (rng.uniform(size=len(k2)) < 0.2).astype(np.uint8)
     add("orbx_search_by_projection_sim3", "ORBmatcher.cc:415-560 (th 10)",
         lambda: m.SearchByProjectionSim3(t2, pts, matched.copy(), 10), lambda: oracle.search_by_projection_sim3(t2, pts, matched.copy(), 10))
