@@ -171,6 +171,7 @@ def main():
                     help="collective for the per-frame keypoint records: to rank 0 (default) or to every rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive secondary figure (host_io)")
     ap.add_argument("--stages", action="store_true", help="also print a per-kernel table to stderr")
     args = ap.parse_args()
 
@@ -466,6 +467,26 @@ def main():
                                    "sample": f"{nsample} {'stereo frames' if stereo else 'frames'} of the same synthetic stream, "
                                              f"single-thread CPU oracle (extract{' x2 + ComputeStereoMatches' if stereo else ' + brute-force match'}), "
                                              f"{'pinned to one core' if pinned else 'not pinned'}, host has {os.cpu_count()} cores"}
+        if not stereo and not args.no_host_io:
+            # secondary figure: the same extraction fed from HOST memory through orbx_extract_batch (page-locked buffers, one chunk
+            # per call: upload, kernels and download in series -- the best page-locked form on this stack, profiles/
+            # r03_host_io_trace.txt), PCIe inclusive.  Never `value`.
+            nh = min(B, 256)
+            exh = ORBextractor(NF, 1.2, 8, 20, 7, max_batch=nh, device=local_rank)
+            keep = [_capi.PinnedArray((nh, H, W)), _capi.PinnedArray((nh, cap), _capi.KP_DTYPE), _capi.PinnedArray((nh, cap, 32)),
+                    _capi.PinnedArray((nh,), np.int32)]
+            himg, hk, hd, hc = (k.array for k in keep)
+            himg[...] = frames[:nh]
+            hcall = lambda: _capi.check(L.orbx_extract_batch(exh.handle, nh, _capi.ptr(himg), W, H, W, W * H, _capi.ptr(hk), _capi.ptr(hd), _capi.ptr(hc), cap))
+            hcall(); hcall()
+            th = time.perf_counter()
+            for _ in range(5):
+                hcall()
+            th = (time.perf_counter() - th) / 5
+            out["host_io"] = {"value": round(nh / th, 1), "unit": "frames/s", "frames_per_call": nh, "ms_per_call": round(th * 1e3, 3),
+                              "memory": "page-locked host buffers in and out (orbx_host_alloc), one chunk per call, extraction only",
+                              "bytes_per_frame": int(W * H + cap * 60 + 4)}
+            del exh
         if args.stages:
             for k, v in prof.items():
                 print(f"  {k:14s} {v[0] / 2:9.4f} ms/step  ({v[1] // 2} launches/step)", file=sys.stderr)
