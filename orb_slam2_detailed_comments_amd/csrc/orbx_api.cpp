@@ -49,8 +49,6 @@ struct orbx_handle {
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     OrbxCell *d_cells = nullptr;
     OrbxFastGroup *d_groups = nullptr;
-    OrbxPyrStrip *d_pyr_strips = nullptr;   // k_pyr_pair work items of every paired level
-    bool pyr_pairs = true;                  // ORBX_PYR_PAIR=0: one launch per level (A/B runs)
     bool resize_legacy = false;   // ORBX_RESIZE_IMPL=legacy: k_pyr_resize for every level (A/B runs)
     bool match_valu = false;      // ORBX_MATCH_KERNEL=valu, read ONCE when the handle is created: the vector-pipe matcher (A/B runs, parity tests)
     int fast_stop = 0;      // ORBX_FAST_STOP: only read in -DORBX_TIMING_KNOBS builds
@@ -177,7 +175,6 @@ static orbx_status pin_reserve(orbx_handle *h, size_t bytes);   // page-locked h
 // ---------------------------------------------------------------- workspace
 static void free_geometry_buffers(orbx_handle *h) {
     hipFree(h->d_groups); h->d_groups = nullptr;
-    hipFree(h->d_pyr_strips); h->d_pyr_strips = nullptr;
     hipFree(h->d_pyr); hipFree(h->d_blur); hipFree(h->d_cells); hipFree(h->d_taps);
     hipFree(h->d_dense); h->d_dense = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_lvl_count); hipFree(h->d_status); hipFree(h->d_lvl_kp);
@@ -265,18 +262,6 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     // with a non-blocking stream -- the round-1 race -- and a device-wide barrier would stall every other handle).
     // Source vectors live in h->geom (they outlive the copies).
     if (const char *e = getenv("ORBX_RESIZE_IMPL")) h->resize_legacy = strcmp(e, "legacy") == 0;
-    if (const char *e = getenv("ORBX_PYR_PAIR")) h->pyr_pairs = atoi(e) != 0;
-    {   // level pairs whose LDS image does not fit a CU fall back to one launch per level
-        size_t need = 0;
-        for (int m = 2; m < NL; m += 2) {
-            OrbxLevelGeom &M = h->geom.lv[m];
-            if (M.pair_strip_count == 0) continue;
-            const size_t smem = (size_t)M.pair_lds_rows * (((size_t)h->geom.lv[m - 1].pw + 12 + 15) & ~(size_t)15) + 16;
-            if (smem > (size_t)150 * 1024) { M.pair_strip_count = 0; continue; }
-            need = std::max(need, smem);
-        }
-        if (need > (size_t)64 * 1024) HIPCHK(orbx_pyr_pair_prepare(need));
-    }
 #ifdef ORBX_TIMING_KNOBS   // phase-timing builds only (tools/build_variant.sh): stops k_fast_rows early, results are wrong
     if (const char *e = getenv("ORBX_FAST_STOP")) h->fast_stop = atoi(e);
 #endif
@@ -309,9 +294,6 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
         ORBX_TRY(hipMalloc(&h->d_lvl_kp, (size_t)B * hg.kp_total * sizeof(uint32_t)));
         ORBX_TRY(hipMalloc(&h->d_lvl_angle, (size_t)B * hg.kp_total * sizeof(float)));
         ORBX_TRY(hipMalloc(&h->d_groups, std::max<size_t>(1, hg.fast_groups.size()) * sizeof(OrbxFastGroup)));
-        ORBX_TRY(hipMalloc(&h->d_pyr_strips, std::max<size_t>(1, hg.pyr_strips.size()) * sizeof(OrbxPyrStrip)));
-        if (!hg.pyr_strips.empty())
-            ORBX_TRY(hipMemcpyAsync(h->d_pyr_strips, hg.pyr_strips.data(), hg.pyr_strips.size() * sizeof(OrbxPyrStrip), hipMemcpyHostToDevice, s));
         if (!hg.cells.empty()) {
             ORBX_TRY(hipMemcpyAsync(h->d_cells, hg.cells.data(), hg.cells.size() * sizeof(OrbxCell), hipMemcpyHostToDevice, s));
             ORBX_TRY(hipMemcpyAsync(h->d_groups, hg.fast_groups.data(), hg.fast_groups.size() * sizeof(OrbxFastGroup),
@@ -506,26 +488,18 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
     const int ngroups = (int)h->geom.fast_groups.size();
     const bool fork = h->fork_level > 0 && (long long)B * ngroups >= 16384;
     const int l_main_end = fork ? h->fork_level : NL;
-    // levels [lb, le) of the resize chain: a level pair (m-1, m) that lies inside the range goes through k_pyr_pair
-    auto resize_range = [&](hipStream_t st, int lb, int le) {
-        for (int l = lb; l < le;) {
-            ProfScope ps(h, ORBX_K_PYR_RESIZE, st);
-            const OrbxLevelGeom &M = h->geom.lv[std::min(l + 1, NL - 1)];
-            if (h->pyr_pairs && !h->resize_legacy && (l & 1) && l + 1 < le && M.pair_strip_count > 0) {
-                orbx_launch_pyr_pair(st, g, B, l + 1, h->d_taps, h->d_pyr, h->d_pyr_strips + M.pair_strip_begin, M.pair_strip_count, M.pair_lds_rows);
-                l += 2;
-            } else {
-                orbx_launch_pyr_resize(st, g, B, l, h->d_taps, h->d_pyr, h->geom.lv[l].narrow_taps && !h->resize_legacy);
-                l += 1;
-            }
-        }
-    };
-    resize_range(s, 1, l_main_end);
+    for (int l = 1; l < l_main_end; ++l) {
+        ProfScope ps(h, ORBX_K_PYR_RESIZE);
+        orbx_launch_pyr_resize(s, g, B, l, h->d_taps, h->d_pyr, h->geom.lv[l].narrow_taps && !h->resize_legacy);
+    }
     if (fork) {
         hipStream_t s2 = h->side_stream;
         if (hipEventRecord(h->ev_fork, s) != hipSuccess || hipStreamWaitEvent(s2, h->ev_fork, 0) != hipSuccess)
             return fail(ORBX_HIP_ERROR, "fork event");
-        resize_range(s2, h->fork_level, NL);
+        for (int l = h->fork_level; l < NL; ++l) {
+            ProfScope ps(h, ORBX_K_PYR_RESIZE, s2);
+            orbx_launch_pyr_resize(s2, g, B, l, h->d_taps, h->d_pyr, h->geom.lv[l].narrow_taps && !h->resize_legacy);
+        }
         { ProfScope ps(h, ORBX_K_FAST, s2);
           orbx_launch_fast_rows(s2, g, B, h->d_cells, h->d_groups + h->fork_group, ngroups - h->fork_group, h->d_pyr, h->d_dense,
                                 h->d_cand_count, d_status, h->max_ch, h->fast_lcap, h->fast_stop); }

@@ -185,36 +185,6 @@ orbx_status orbx_build_geometry(const orbx_params &p, const OrbxTables &t, int w
             }
         }
     }
-    // Level pairs of k_pyr_pair: (1, 2), (3, 4), ... -- level m-1 goes through LDS on its way to level m.  Strips of
-    // ORBX_PYR_STRIP_ROWS destination rows of level m; the rows of level m-1 a strip needs are the span of its vertical taps
-    // (border rows of level m reflect into rows its centre also uses, so the span is one interval), extended to the rows the
-    // strip OWNS: the centre rows of level m map monotonically onto all rows of the padded level m-1, so the strip that holds
-    // centre rows [ca, cb) owns [s0(ca), s0(cb)) -- from row 0 for the first centre row, to the last row for the last.
-    for (int l = 0; l < g.nlevels; ++l) g.lv[l].pair_strip_begin = g.lv[l].pair_strip_count = g.lv[l].pair_lds_rows = 0;
-    for (int m = 2; m < g.nlevels; m += 2) {
-        OrbxLevelGeom &M = g.lv[m];
-        const OrbxLevelGeom &L = g.lv[m - 1];
-        if (!M.narrow_taps || !L.narrow_taps || M.ph < 2 * ORBX_EDGE + 1 || L.ph > 32000) continue;
-        M.pair_strip_begin = (int)g.pyr_strips.size();
-        const OrbxTap *ty = &g.taps[(size_t)M.tapy_begin];
-        const int c_first = ORBX_EDGE, c_end = M.ph - ORBX_EDGE;   // centre rows of level m
-        for (int a = 0; a < M.ph; a += ORBX_PYR_STRIP_ROWS) {
-            const int b = std::min(M.ph, a + ORBX_PYR_STRIP_ROWS);
-            int r0 = 0x7fff, r1 = -1;
-            for (int y = a; y < b; ++y) { r0 = std::min<int>(r0, ty[y].s0); r1 = std::max<int>(r1, ty[y].s1); }
-            const int ca = std::max(a, c_first), cb = std::min(b, c_end);
-            int own_lo = 0, own_hi = 0;
-            if (ca < cb) {
-                own_lo = ca == c_first ? 0 : ty[ca].s0;
-                own_hi = cb == c_end ? L.ph : ty[cb].s0;
-                if (own_hi > own_lo) { r0 = std::min(r0, own_lo); r1 = std::max(r1, own_hi - 1); }
-            }
-            OrbxPyrStrip st = {(int16_t)a, (int16_t)b, (int16_t)r0, (int16_t)r1, (int16_t)own_lo, (int16_t)own_hi};
-            g.pyr_strips.push_back(st);
-            M.pair_lds_rows = std::max(M.pair_lds_rows, r1 - r0 + 1);
-        }
-        M.pair_strip_count = (int)g.pyr_strips.size() - M.pair_strip_begin;
-    }
     // FAST wave groups: pair a cell with its right-hand neighbour when both interiors fit the 64 lanes of a wave plus the
     // ORBX_FAST_XCOLS columns k_fast_rows tests outside its row walk (two 33-column cells: 66)
     for (size_t i = 0; i < g.cells.size();) {

@@ -35,14 +35,6 @@ struct OrbxTap {
     int16_t a0, a1;  // 11-bit fixed-point weights
 };
 
-// One workgroup of k_pyr_pair: destination rows [a, b) of padded level m, computed from rows [r0, r1] of padded level m-1 that the
-// same workgroup first resizes from level m-2 into LDS; of those it writes rows [own_lo, own_hi) to the pyramid (every row of
-// level m-1 is owned by exactly one strip).
-struct OrbxPyrStrip { int16_t a, b, r0, r1, own_lo, own_hi; };
-#ifndef ORBX_PYR_STRIP_ROWS
-#define ORBX_PYR_STRIP_ROWS 32   // destination rows per workgroup
-#endif
-
 struct OrbxLevelGeom {
     int sw, sh;          // un-padded size
     int pw, ph, pitch;   // padded size and row pitch in bytes
@@ -59,7 +51,6 @@ struct OrbxLevelGeom {
     int64_t cand_begin;  // offset inside the per-frame candidate table
     int tapx_begin, tapy_begin;  // offsets into the tap table (level > 0)
     bool narrow_taps;    // every aligned group of 4 destination columns reads <= 8 consecutive source bytes (k_pyr_resize_rows)
-    int pair_strip_begin, pair_strip_count, pair_lds_rows;   // k_pyr_pair work items that produce THIS level together with the one before it (count 0: not paired)
     float scale;         // mvScaleFactor[level]
     float size;          // (float)(int)(31 * scale)
 };
@@ -70,7 +61,6 @@ struct OrbxGeom {
     std::vector<OrbxCell> cells;
     std::vector<OrbxFastGroup> fast_groups;
     std::vector<OrbxTap> taps;
-    std::vector<OrbxPyrStrip> pyr_strips;
     int64_t pyr_bytes = 0;     // per frame
     int64_t cand_total = 0;    // per frame
     int kp_total = 0;          // per frame: sum of kp_cap

@@ -403,154 +403,6 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_pyr_pair: levels m-1 AND m in one launch (round 3).  The resize chain was seven DEPENDENT launches, each reading the level
-// the launch before it had just written; here a workgroup owns a strip of ORBX_PYR_STRIP_ROWS destination rows of level m:
-//   phase A  resizes the rows of level m-1 that strip needs (the span of its vertical taps, ~1.2 x 32 + 2 rows, full padded
-//            width) from level m-2 into LDS, and writes the rows it OWNS (OrbxPyrStrip) to the pyramid;
-//   phase B  resizes the strip's rows of level m from that LDS image.
-// Level m-1 is written once and never read back from HBM by the chain (levels 1, 3, 5 of an 8-level pyramid: a quarter of the
-// chain's traffic), and the chain is 1 + 4 launches instead of 1 + 7.  Both phases are the row walk of k_pyr_resize_rows (same
-// taps, same integer arithmetic: rr_walk below is that kernel's body with the source and destination address spaces as
-// parameters); a column strip of 256 pixels is walked by RSPLIT waves, each taking a share of the rows.  The 2-3 source rows
-// two neighbouring strips both need are computed by both (6 % of level m-1).
-// ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) const orbx_uint3_a rr_lds_c3;
-typedef __attribute__((address_space(3))) uint32_t rr_lds_u32;
-template <bool SRC_LDS>
-__device__ __forceinline__ orbx_uint3_a rr_load12(const uint8_t *g, uint32_t l) {   // 12 bytes at a dword-aligned global / LDS address
-    orbx_uint3_a v;
-    if (SRC_LDS) {
-        const rr_lds_c3 *p = (const rr_lds_c3 *)(uintptr_t)l;
-        v.x = p->x; v.y = p->y; v.z = p->z;
-    } else {
-        v = *(const orbx_uint3_a *)g;
-    }
-    return v;
-}
-template <bool SRC_LDS, bool DST_LDS>
-__device__ __forceinline__ void rr_walk(const OrbxTap *__restrict__ taps, int tapx, int tapy, int pw,          // destination level
-                                        const uint8_t *__restrict__ src_g, int src_pitch_g,                    // source rows in global memory ...
-                                        uint32_t src_l, int src_pitch_l, int src_row0,                         // ... or in LDS (row s at src_l + (s - src_row0) * pitch)
-                                        uint8_t *__restrict__ dst_g, int dst_pitch_g, int own_lo, int own_hi,  // rows [own_lo, own_hi) go to global memory
-                                        uint32_t dst_l, int dst_pitch_l, int dst_row0,                         // DST_LDS: every row also goes to LDS
-                                        int y_begin, int y_end, int X) {
-    const bool on = X < pw;
-    uint32_t sel[4], wgt[4];
-    int smin = 0x7fff;
-    {
-        const uint2 *tq = (const uint2 *)taps + tapx;
-        uint2 t[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] = tq[min(X + i, pw - 1)];   // .x = s0 | s1 << 16, .y = a0 | a1 << 16
-#pragma unroll
-        for (int i = 0; i < 4; ++i) smin = min(smin, (int)(t[i].x & 0xffffu));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t d = (t[i].x & 0xffffu) - (uint32_t)smin;          // 0..6 (checked on the host)
-            sel[i] = d | (0x0cu << 8) | ((d + 1u) << 16) | (0x0cu << 24);
-            wgt[i] = t[i].y;
-        }
-    }
-    const uint32_t sh = (uint32_t)(smin & 3);
-    const int xoff = smin & ~3;
-    const uint2 *ty = (const uint2 *)taps + tapy;
-#define RRW_LOAD(s) rr_load12<SRC_LDS>(src_g + (SRC_LDS ? 0ll : (long long)(s) * src_pitch_g + xoff),                                   \
-                                       src_l + (uint32_t)(SRC_LDS ? ((s) - src_row0) * src_pitch_l + xoff : 0))
-#define RRW_H(dst, v)                                                                                                    \
-    {                                                                                                                   \
-        const uint32_t lo_ = __builtin_amdgcn_alignbyte((v).y, (v).x, sh), hi_ = __builtin_amdgcn_alignbyte((v).z, (v).y, sh); \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
-            dst[i] = orbx_udot2(__builtin_amdgcn_perm(hi_, lo_, sel[i]), wgt[i]) >> 4;                                  \
-    }
-#define RRW_V(out, h0, h1, w0, w1)                                                                                      \
-    {                                                                                                                   \
-        out = 0;                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
-            out |= (((__umul24(w0, h0[i]) >> 16) + (__umul24(w1, h1[i]) >> 16) + 2u) >> 2) << (8 * i);                  \
-    }
-    uint2 t[2];
-    orbx_uint3_a u[2], w[2];
-    int pid = -1;                                   // source row whose horizontal pass hb[0] holds at the top of a step
-    uint32_t hb[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    const int ylast = y_end - 1;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        t[r] = ty[min(y_begin + r, ylast)];
-        u[r].x = u[r].y = u[r].z = 0;
-        if (r == 0 || (int)(t[r].x & 0xffffu) != (int)(t[r - 1].x >> 16)) u[r] = RRW_LOAD((int)(t[r].x & 0xffffu));
-        w[r] = RRW_LOAD((int)(t[r].x >> 16));
-    }
-    for (int Y = y_begin; Y < y_end; Y += 2) {
-        uint2 ct[2];
-        orbx_uint3_a cu[2], cw[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) { ct[r] = t[r]; cu[r] = u[r]; cw[r] = w[r]; }
-        if (Y + 2 < y_end) {   // next step's rows, in flight while this step is evaluated; rows this step leaves in registers are skipped
-            int last = (int)(ct[1].x >> 16);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                t[r] = ty[min(Y + 2 + r, ylast)];
-                const int s0 = (int)(t[r].x & 0xffffu), s1 = (int)(t[r].x >> 16);
-                if (s0 != last) u[r] = RRW_LOAD(s0);
-                w[r] = RRW_LOAD(s1);
-                last = s1;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            uint32_t (&h0)[4] = hb[r & 1], (&h1)[4] = hb[(r & 1) ^ 1];
-            const int s0 = (int)(ct[r].x & 0xffffu);
-            if (s0 != pid) RRW_H(h0, cu[r])
-            RRW_H(h1, cw[r])
-            uint32_t v;
-            RRW_V(v, h0, h1, ct[r].y & 0xfffu, (ct[r].y >> 16) & 0xfffu)
-            pid = (int)(ct[r].x >> 16);
-            if (on && Y + r < y_end) {
-                if (DST_LDS) *(rr_lds_u32 *)(uintptr_t)(dst_l + (uint32_t)((Y + r - dst_row0) * dst_pitch_l + X)) = v;
-                if (Y + r >= own_lo && Y + r < own_hi) *(uint32_t *)(dst_g + (long long)(Y + r) * dst_pitch_g + X) = v;
-            }
-        }
-    }
-#undef RRW_LOAD
-#undef RRW_H
-#undef RRW_V
-}
-
-template <int RSPLIT>
-__global__ __launch_bounds__(1024) void k_pyr_pair(DGeom g, int m, const OrbxTap *__restrict__ taps, uint8_t *__restrict__ pyr,
-                                                   const OrbxPyrStrip *__restrict__ strips, int lds_pitch, int ncols) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t pp_smem[];
-    const DLevel &M = g.lv[m];
-    const DLevel &L = g.lv[m - 1];
-    const DLevel &S = g.lv[m - 2];
-    const int f = blockIdx.x;
-    const OrbxPyrStrip st = strips[blockIdx.y];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col = wv % ncols, part = wv / ncols;            // column strip of 256 pixels, share of the rows
-    const int X = (col * 64 + lane) * 4;
-    uint8_t *base = pyr + (long long)f * g.pyr_bytes;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)pp_smem;
-    // phase A: rows [r0, r1] of level m-1 from level m-2 (even row counts per share: the walk takes two rows per step)
-    {
-        const int n = st.r1 + 1 - st.r0, per = ((n + RSPLIT - 1) / RSPLIT + 1) & ~1;
-        const int ya = st.r0 + part * per, yb = min(st.r1 + 1, ya + per);
-        if (col * 256 < L.pw && ya < yb)
-            rr_walk<false, true>(taps, L.tapx, L.tapy, L.pw, base + S.off, S.pitch, 0u, 0, 0, base + L.off, L.pitch, st.own_lo, st.own_hi,
-                                 lds0, lds_pitch, st.r0, ya, yb, X);
-    }
-    __syncthreads();
-    // phase B: rows [a, b) of level m from the LDS image of level m-1
-    {
-        const int n = st.b - st.a, per = ((n + RSPLIT - 1) / RSPLIT + 1) & ~1;
-        const int ya = st.a + part * per, yb = min((int)st.b, ya + per);
-        if (col * 256 < M.pw && ya < yb)
-            rr_walk<true, false>(taps, M.tapx, M.tapy, M.pw, nullptr, 0, lds0, lds_pitch, st.r0, base + M.off, M.pitch, 0, 0x7fff,
-                                 0u, 0, 0, ya, yb, X);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // K2: FAST-9/16 + score + 3x3 strict NMS per cell, with the per-cell threshold retry
 // (reference src/ORBextractor.cc:1465-1548; cv::FAST semantics SURVEY App. B.1): helpers, then k_fast_rows.
 // ------------------------------------------------------------------------------------------------
@@ -2571,23 +2423,6 @@ void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, con
     }
     dim3 grid((L.pw + 255) / 256, (L.ph + 4 * RS_ROWS - 1) / (4 * RS_ROWS), B);
     hipLaunchKernelGGL(k_pyr_resize, grid, dim3(64, 4), 0, s, g, level, taps, pyr);
-}
-void orbx_launch_pyr_pair(hipStream_t s, const DGeom &g, int B, int m, const OrbxTap *taps, uint8_t *pyr, const OrbxPyrStrip *strips,
-                          int nstrips, int lds_rows) {
-    const DLevel &L = g.lv[m - 1];
-    const int ncols = (L.pw + 255) / 256;                    // level m-1 is the wider of the two
-    const int lds_pitch = (L.pw + 12 + 15) & ~15;            // a lane's 12-byte window may start at the row's last aligned dword
-    const size_t smem = (size_t)lds_rows * lds_pitch + 16;
-    // two waves per column strip (each walks half of the rows of both phases) while the workgroup stays within 1024 threads
-    if (2 * ncols <= 16)
-        hipLaunchKernelGGL(k_pyr_pair<2>, dim3(B, nstrips), dim3(64 * 2 * ncols), smem, s, g, m, taps, pyr, strips, lds_pitch, ncols);
-    else
-        hipLaunchKernelGGL(k_pyr_pair<1>, dim3(B, nstrips), dim3(64 * ncols), smem, s, g, m, taps, pyr, strips, lds_pitch, ncols);
-}
-hipError_t orbx_pyr_pair_prepare(size_t smem) {   // dynamic LDS beyond the 64 KB default (very wide levels) must be announced
-    hipError_t e = hipFuncSetAttribute((const void *)k_pyr_pair<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_pyr_pair<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    return e;
 }
 void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *groups,
                            int ngroups, const uint8_t *pyr, uint2 *cand, int *cand_cursor, int *status, int max_ch, int lcap,

@@ -14,9 +14,6 @@ void orbx_launch_pyr_l0_color(hipStream_t s, const DGeom &g, int B, const uint8_
 void orbx_launch_pyr_l0_remap(hipStream_t s, const DGeom &g, int B, const uint8_t *imgs, int W, int H, int stride,
                               long long frame_stride, uint8_t *pyr, const uint2 *rect, int *status, int *cand_cursor);
 void orbx_launch_pyr_resize(hipStream_t s, const DGeom &g, int B, int level, const OrbxTap *taps, uint8_t *pyr, bool narrow);
-void orbx_launch_pyr_pair(hipStream_t s, const DGeom &g, int B, int m, const OrbxTap *taps, uint8_t *pyr, const OrbxPyrStrip *strips,
-                          int nstrips, int lds_rows);
-hipError_t orbx_pyr_pair_prepare(size_t smem);
 void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell *cells, const OrbxFastGroup *groups,
                            int ngroups, const uint8_t *pyr, uint2 *cand, int *cand_cursor, int *status, int max_ch, int lcap,
                            int dbg_stop);

@@ -40,22 +40,6 @@ static void one(int w, int h, int nf, float sf, int nl) {
             for (int y = 0; y < L.ph; ++y) { const OrbxTap &T = g.taps[(size_t)L.tapy_begin + y]; CHECK(T.s0 >= 0 && T.s1 < S.ph && T.s0 <= T.s1 && T.a0 + T.a1 == 2048); }
         }
     }
-    // k_pyr_pair strips: destination rows partitioned; every row of the LDS level owned exactly once, inside the computed span,
-    // which also covers every vertical tap of the strip
-    for (int m = 2; m < nl; m += 2) {
-        const OrbxLevelGeom &M = g.lv[m], &Lm = g.lv[m - 1];
-        if (M.pair_strip_count == 0) continue;
-        int next_a = 0, next_own = 0;
-        for (int k = 0; k < M.pair_strip_count; ++k) {
-            const OrbxPyrStrip &S = g.pyr_strips[(size_t)M.pair_strip_begin + k];
-            CHECK(S.a == next_a && S.b > S.a && S.b <= M.ph && S.b - S.a <= ORBX_PYR_STRIP_ROWS);
-            next_a = S.b;
-            CHECK(S.r0 >= 0 && S.r1 < Lm.ph && S.r1 - S.r0 + 1 <= M.pair_lds_rows);
-            for (int y = S.a; y < S.b; ++y) { const OrbxTap &T = g.taps[(size_t)M.tapy_begin + y]; CHECK(T.s0 >= S.r0 && T.s1 <= S.r1); }
-            if (S.own_hi > S.own_lo) { CHECK(S.own_lo == next_own && S.own_lo >= S.r0 && S.own_hi - 1 <= S.r1); next_own = S.own_hi; }
-        }
-        CHECK(next_a == M.ph && next_own == Lm.ph);
-    }
     for (const OrbxFastGroup &G : g.fast_groups) {
         CHECK(G.ncell == 1 || G.ncell == 2);
         const OrbxCell &a = g.cells[(size_t)G.cell0], &b = g.cells[(size_t)G.cell0 + G.ncell - 1];
