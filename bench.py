@@ -198,9 +198,14 @@ def main():
     NS = 1 if stereo else max(1, args.streams)
     L = _capi.lib()
     right = None
-    if stereo:   # 8 distinct synthetic pairs (right = left scene re-rendered with per-rectangle disparity), repeated to fill the batch
+    if stereo:
+        # 8 rendered synthetic pairs (right = left scene re-rendered with per-rectangle disparity; 0.3 s each) fill the batch as B
+        # DISTINCT images: pair i is base pair i % 8 rolled by (5 i, 11 i) pixels, both eyes alike (the epipolar geometry holds, the
+        # wrap-around seam is one more edge).  A batch of 8 repeated pairs would sit in the 256 MB memory-side cache and make the
+        # level-0 source reads look cheaper than a real stream's.
         base = [synth.stereo_pair(W, H, stream_id=70 + 8 * rank + i) for i in range(8)]
-        frames = np.stack([base[i % 8][0] for i in range(B)]); right = np.stack([base[i % 8][1] for i in range(B)])
+        roll = lambda im, i: im if i < 8 else np.roll(im, (5 * i % H, 11 * i % W), axis=(0, 1))
+        frames = np.stack([roll(base[i % 8][0], i) for i in range(B)]); right = np.stack([roll(base[i % 8][1], i) for i in range(B)])
     else:
         frames = synth.stream(W, H, B, stream_id=100 + rank)
     d_imgs = torch.from_numpy(frames).to(dev)
@@ -467,7 +472,7 @@ def main():
                                    "sample": f"{nsample} {'stereo frames' if stereo else 'frames'} of the same synthetic stream, "
                                              f"single-thread CPU oracle (extract{' x2 + ComputeStereoMatches' if stereo else ' + brute-force match'}), "
                                              f"{'pinned to one core' if pinned else 'not pinned'}, host has {os.cpu_count()} cores"}
-        if not stereo and not args.no_host_io:
+        if not stereo and not args.no_host_io and world == 1:
             # secondary figure: the same extraction fed from HOST memory through orbx_extract_batch (page-locked buffers, one chunk
             # per call: upload, kernels and download in series -- the best page-locked form on this stack, profiles/
             # r03_host_io_trace.txt), PCIe inclusive.  Never `value`.

@@ -189,7 +189,11 @@ static orbx_status configure(orbx_handle *h, int width, int height) {
     if (h->configured && h->geom.width == width && h->geom.height == height) return ORBX_OK;
     if (h->host_only) return fail(ORBX_NO_DEVICE, "host-only handle (device = -2) cannot extract");
     HIPCHK(hipSetDevice(h->dev));
-    if (h->configured) { HIPCHK(hipStreamSynchronize(h->stream)); free_geometry_buffers(h); }
+    if (h->configured) {   // nothing queued on either of the handle's streams may still read the buffers that are about to go
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->side_stream) HIPCHK(hipStreamSynchronize(h->side_stream));
+        free_geometry_buffers(h);
+    }
     const char *why = "";
     OrbxGeom g;
     orbx_status st = orbx_build_geometry(h->p, h->tab, width, height, g, &why);
@@ -510,7 +514,7 @@ static orbx_status run_chunk(orbx_handle *h, int B, const uint8_t *d_imgs, int W
           orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, h->fork_group, h->d_pyr, h->d_dense,
                                 h->d_cand_count, d_status, h->max_ch, h->fast_lcap, h->fast_stop); }
         if (hipEventRecord(h->ev_join, s2) != hipSuccess || hipStreamWaitEvent(s, h->ev_join, 0) != hipSuccess)
-            return fail(ORBX_HIP_ERROR, "join event");
+            { hipStreamSynchronize(s2); return fail(ORBX_HIP_ERROR, "join event"); }   // the side stream's work reads the handle's buffers: never leave it unjoined
     } else {
         ProfScope ps(h, ORBX_K_FAST);
         orbx_launch_fast_rows(s, g, B, h->d_cells, h->d_groups, ngroups, h->d_pyr, h->d_dense,
