@@ -72,6 +72,37 @@ while time.time() - t0 < budget:
                 j = int(rng.integers(0, len(want)))
                 assert int(got[j] >> 16) == oracle.descriptor_distance(qd[i], dL[want[j]]), f"gate distance: {tag}"
         ng = globals().get("ng", 0) + nq
+    # ---- batched Fuse (orbx_fuse_batch / orbx_fuse_sim3_batch): K random (keyframe, projected points) problems in one call, per
+    # problem against the oracle's single Fuse; keyframes = the two eyes' features cut to random sizes (some empty), point sets
+    # shared between problems (SearchInNeighbors) or not, both fp modes of the chi2 gate through the extractor's own mode
+    if len(kL) and len(kR):
+        sfac = exL.GetScaleFactors(); isig = exL.GetInverseScaleSigmaSquares()
+        def target(k, d):
+            nkeep = int(rng.integers(0, len(k) + 1))
+            return dict(keys_un=k[:nkeep], desc=d[:nkeep], bounds=(0.0, float(w + 38), 0.0, float(h + 38)), scale_factors=sfac, inv_level_sigma2=isig,
+                        u_right=np.where(rng.uniform(size=nkeep) < 0.4, k["x"][:nkeep] - rng.uniform(2, 30, nkeep), -1).astype(np.float32))
+        def points(k, d):
+            npt = int(rng.integers(0, 600))
+            idx = rng.integers(0, len(k), npt)
+            uv = np.stack([k["x"][idx], k["y"][idx]], 1).astype(np.float32) + rng.normal(0, 2.0, (npt, 2)).astype(np.float32)
+            dd = d[idx].copy()
+            if npt: dd[rng.integers(0, npt, npt // 2), rng.integers(0, 32, npt // 2)] ^= np.uint8(1 << int(rng.integers(0, 8)))
+            return dict(valid=(rng.uniform(size=npt) < 0.85).astype(np.uint8), uv=uv, level=np.clip(k["octave"][idx] + rng.integers(0, 2, npt), 0, nl - 1).astype(np.int32),
+                        desc=dd, u_right=(uv[:, 0] - rng.uniform(2, 30, npt)).astype(np.float32) if npt else np.zeros(0, np.float32))
+        K = int(rng.integers(1, 7))
+        tgs = [target(*((kL, dL) if rng.uniform() < 0.5 else (kR, dR))) for _ in range(K)]
+        shared = points(kL, dL)
+        pts_l = [shared if rng.uniform() < 0.6 else points(kR, dR) for _ in range(K)]
+        mm = ORBmatcher(0.6, True, extractor=exL)
+        for sim3, th in ((False, float(rng.choice([2.0, 3.0, 5.0]))), (True, float(rng.choice([3.0, 4.0, 8.0])))):
+            cnts, bests = mm.FuseBatch(tgs, pts_l, th, sim3=sim3)
+            for kq in range(K):
+                if len(tgs[kq]["keys_un"]) == 0 or len(pts_l[kq]["valid"]) == 0:
+                    assert cnts[kq] == 0 and (bests[kq] == -1).all(), f"empty problem {kq}: {tag}"
+                    continue
+                on_, ob_ = oracle.fuse_sim3(tgs[kq], pts_l[kq], th) if sim3 else oracle.fuse(tgs[kq], pts_l[kq], th, 0)
+                assert cnts[kq] == on_ and np.array_equal(bests[kq], ob_), f"fuse batch problem {kq} of {K} sim3={sim3} th={th}: {tag}"
+            globals()["nfb"] = globals().get("nfb", 0) + K
     if ns % 20 == 0: print(f"  .. {ns} stereo pairs, {nm} descriptor sets, {time.time() - t0:.0f} s", flush=True)
-print(f"gated candidate queries compared: {globals().get('ng', 0)}")
+print(f"gated candidate queries compared: {globals().get('ng', 0)}; batched Fuse problems compared: {globals().get('nfb', 0)}")
 print(f"policy soak ok: {ns} random stereo pairs ({skipped} unsupported geometries skipped), {nm} random descriptor-set matches in {time.time() - t0:.0f} s")
