@@ -64,8 +64,9 @@ struct orbx_handle {
     uint8_t *st_in[2] = {nullptr, nullptr}; size_t d_in_bytes = 0;
     orbx_keypoint *st_kps[2] = {nullptr, nullptr}; uint8_t *st_desc[2] = {nullptr, nullptr}; int *st_cnt[2] = {nullptr, nullptr};
     int out_cap = 0, stage_chunk = 0;
-    hipStream_t s_in = nullptr, s_out = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    int *pin_stat = nullptr; size_t pin_stat_ints = 0;   // page-locked landing place of the per-frame counts | status words of a call (grow-only)
+    hipStream_t s_in = nullptr;   // the ONE copy stream of the pipelined host-buffer call (uploads and downloads in turn)
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     int last_batch = 0;
     int mk_w = 0, mk_h = 0, mk_total = 0;   // orbx_max_keypoints cache
     void *d_match_ws = nullptr; size_t match_ws_bytes = 0;   // partial (best, second) keys of k_match
@@ -379,13 +380,14 @@ extern "C" void orbx_destroy(orbx_handle *h) {
         free_geometry_buffers(h);
         hipFree(h->d_match_ws); hipFree(h->d_scratch); hipFree(h->d_rect); hipFree(h->d_gate_items);
         if (h->pin) hipHostFree(h->pin);
+        if (h->pin_stat) hipHostFree(h->pin_stat);
         for (int s = 0; s < 2; ++s) {
             hipFree(h->st_in[s]); hipFree(h->st_kps[s]);   // st_desc / st_cnt live inside the st_kps allocation
             if (h->ev_in[s]) hipEventDestroy(h->ev_in[s]);
             if (h->ev_done[s]) hipEventDestroy(h->ev_done[s]);
+            if (h->ev_out[s]) hipEventDestroy(h->ev_out[s]);
         }
         if (h->s_in) hipStreamDestroy(h->s_in);
-        if (h->s_out) hipStreamDestroy(h->s_out);
         if (h->side_stream) { hipStreamSynchronize(h->side_stream); hipStreamDestroy(h->side_stream); }
         if (h->ev_fork) hipEventDestroy(h->ev_fork);
         if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -582,10 +584,10 @@ static orbx_status ensure_staging(orbx_handle *h, size_t in_bytes, int cap, int 
     }
     if (!h->s_in) {
         HIPCHK(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
         for (int s = 0; s < 2; ++s) {
             HIPCHK(hipEventCreateWithFlags(&h->ev_in[s], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_out[s], hipEventDisableTiming));
         }
     }
     return ORBX_OK;
@@ -615,11 +617,24 @@ extern "C" orbx_status orbx_extract_batch(orbx_handle *h, int nframes, const uin
     st = ensure_staging(h, (size_t)chunk * fbytes, cap, chunk);
     if (st != ORBX_OK) return st;
     const int nchunks = (nframes + chunk - 1) / chunk;
-    std::vector<int> hstat((size_t)2 * chunk);
+    // counts | status of every chunk of the call land here (page-locked: a pageable landing place would make each copy
+    // synchronous), one slot per chunk so that nothing is reused before the call's single final wait
+    if ((size_t)2 * nchunks * chunk > h->pin_stat_ints) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->pin_stat) { hipHostFree(h->pin_stat); h->pin_stat = nullptr; h->pin_stat_ints = 0; }
+        HIPCHK(hipHostMalloc((void **)&h->pin_stat, (size_t)2 * nchunks * chunk * sizeof(int), hipHostMallocDefault));
+        h->pin_stat_ints = (size_t)2 * nchunks * chunk;
+    }
+    int *hstat = h->pin_stat;
     orbx_status worst = ORBX_OK;
     // a single chunk needs no second stream: copies and kernels in order on the handle's stream (the latency path)
     const bool piped = nchunks > 1;
-    hipStream_t sin = piped ? h->s_in : h->stream, sout = piped ? h->s_out : h->stream;
+    // Pipelined calls use ONE copy stream for both directions: upload(c+1) and download(c-1) take turns on it while chunk c
+    // computes.  (Round 2 had a second stream for the downloads; with uploads, downloads and kernels all in flight at once the
+    // kernels of chunks >= 1 ran 1.4-5x slower from page-locked caller memory -- profiles/r03_host_io_trace.txt -- and
+    // page-locked memory lost to pageable memory: 88 k against 103 k frames/s.  With one copy stream, the download queued in
+    // front of the next upload and every dependency a stream-side event wait, the copy stream is busy back to back.)
+    hipStream_t sin = piped ? h->s_in : h->stream, sout = sin;
     auto upload = [&](int c) -> hipError_t {
         const int s = c & 1, f0 = c * chunk, B = std::min(chunk, nframes - f0);
         if (c >= 2) {   // the kernels of chunk c-2 read this input set
@@ -638,18 +653,26 @@ extern "C" orbx_status orbx_extract_batch(orbx_handle *h, int nframes, const uin
         }
         return piped ? hipEventRecord(h->ev_in[s], sin) : hipSuccess;
     };
-    auto download = [&](int c) -> hipError_t {
+    // download of chunk c: queued behind the chunk's kernels; its event frees the output set for chunk c+2's kernels
+    auto download_enqueue = [&](int c) -> hipError_t {
         const int s = c & 1, f0 = c * chunk, B = std::min(chunk, nframes - f0);
         hipError_t e = piped ? hipStreamWaitEvent(sout, h->ev_done[s], 0) : hipSuccess;
         if (e == hipSuccess) e = hipMemcpyAsync(kps + (int64_t)f0 * cap, h->st_kps[s], (size_t)B * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, sout);
         if (e == hipSuccess) e = hipMemcpyAsync(desc + (int64_t)f0 * cap * 32, h->st_desc[s], (size_t)B * cap * 32, hipMemcpyDeviceToHost, sout);
-        if (e == hipSuccess) e = hipMemcpyAsync(counts + f0, h->st_cnt[s], (size_t)B * sizeof(int), hipMemcpyDeviceToHost, sout);
-        if (e == hipSuccess) e = hipMemcpyAsync(hstat.data() + (size_t)s * chunk, h->st_cnt[s] + chunk, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, sout);
-        if (e == hipSuccess) e = hipStreamSynchronize(sout);   // the staging set `s` is free again after this
-        if (e == hipSuccess)
-            for (int i = 0; i < B; ++i)
-                if (hstat[(size_t)s * chunk + i] != ORBX_OK) worst = (orbx_status)hstat[(size_t)s * chunk + i];
+        // counts | status are one device block (st_cnt[s][0 .. 2 chunk)): ONE small copy (every copy costs ~15 us of link
+        // turn-around whatever its size); the counts go on to the caller's array from the landing buffer
+        if (e == hipSuccess) e = hipMemcpyAsync(hstat + (size_t)c * 2 * chunk, h->st_cnt[s], (size_t)2 * chunk * sizeof(int), hipMemcpyDeviceToHost, sout);
+        if (e == hipSuccess && piped) e = hipEventRecord(h->ev_out[s], sout);
         return e;
+    };
+    auto collect = [&]() {   // after the final wait: counts to the caller, worst status of the call
+        for (int c = 0; c < nchunks; ++c) {
+            const int f0 = c * chunk, B = std::min(chunk, nframes - f0);
+            for (int i = 0; i < B; ++i) {
+                counts[f0 + i] = hstat[(size_t)c * 2 * chunk + i];
+                if (hstat[(size_t)c * 2 * chunk + chunk + i] != ORBX_OK) worst = (orbx_status)hstat[(size_t)c * 2 * chunk + chunk + i];
+            }
+        }
     };
     // Latency path (one chunk that fills its staging block exactly, a few MB at most -- the drop-in call of Tracking.cc): the
     // frames go through page-locked staging (one true DMA instead of a runtime-staged pageable copy) and the results come
@@ -688,15 +711,25 @@ extern "C" orbx_status orbx_extract_batch(orbx_handle *h, int nframes, const uin
     HIPCHK(upload(0));
     for (int c = 0; c < nchunks; ++c) {
         const int s = c & 1, f0 = c * chunk, B = std::min(chunk, nframes - f0);
-        if (piped) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_in[s], 0));
+        if (piped) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_in[s], 0));             // the chunk's frames have arrived
         st = run_chunk(h, B, h->st_in[s], width, height, stride, (int64_t)fbytes, h->st_kps[s], h->st_desc[s], h->st_cnt[s],
                        h->st_cnt[s] + chunk, cap);
         if (st != ORBX_OK) { hipStreamSynchronize(h->stream); hipStreamSynchronize(sin); return st; }
         if (piped) HIPCHK(hipEventRecord(h->ev_done[s], h->stream));
-        if (c + 1 < nchunks) HIPCHK(upload(c + 1));      // set (c+1)&1 was released by download(c-1) below
-        if (c >= 1) HIPCHK(download(c - 1));
+        // copy stream: results of chunk c-1 first (its kernels are done or nearly so), then the frames of chunk c+1 (its input
+        // set was read by chunk c-1: the download in front of it already waited for that chunk)
+        if (c >= 1) HIPCHK(download_enqueue(c - 1));
+        if (c + 1 < nchunks) HIPCHK(upload(c + 1));
+        // the calling thread stays one chunk ahead of the device, not more: it waits here until chunk c-1's results have left
+        // their output set, which chunk c+1's kernels (enqueued next) write.  (Letting it run ahead of the whole call with
+        // stream-side waits instead was measured: 82 k against 111 k frames/s at chunks of 32, 84 k against 95 k at 16 chunks
+        // of 64 -- many queued cross-stream waits cost more than the wake-ups they save.)
+        if (piped && c >= 1) HIPCHK(hipEventSynchronize(h->ev_out[(c - 1) & 1]));
     }
-    HIPCHK(download(nchunks - 1));
+    HIPCHK(download_enqueue(nchunks - 1));
+    HIPCHK(hipStreamSynchronize(sout));
+    if (piped) HIPCHK(hipStreamSynchronize(h->stream));
+    collect();
     if (worst != ORBX_OK) return fail(worst, "a frame exceeded the keypoint / candidate capacity");
     return ORBX_OK;
 }

@@ -7,10 +7,10 @@ import os, sys, glob, csv
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(mem):
+def run(mem, N=256):
     import numpy as np
     from orb_slam2_detailed_comments_amd import ORBextractor, synth, _capi
-    N, W, H, mb = 256, 640, 480, 64
+    W, H, mb = 640, 480, 64
     frames = np.concatenate([synth.stream(W, H, 64, stream_id=100)] * (N // 64))
     L = _capi.lib()
     ex = ORBextractor(1000, max_batch=mb)
@@ -37,14 +37,15 @@ def summarise(d):
     ev.sort()
     # the last call = the events after the last gap > 1 ms... take the last quarter of the level-0 launches (4 calls x 4 chunks)
     l0 = [e for e in ev if e[2].startswith("k_pyr_l0")]
-    t0 = l0[-4][0] - 600000 if len(l0) >= 4 else ev[0][0]
+    nch = int(sys.argv[2]) if len(sys.argv) > 2 else 4   # chunks per call
+    t0 = l0[-nch][0] - 600000 if len(l0) >= nch else ev[0][0]
     ev = [e for e in ev if e[0] >= t0]
     base = ev[0][0]
     for s, e, name, is_k in ev:
-        if not is_k or name.startswith(("k_pyr_l0", "k_describe")):
+        if not is_k or name.startswith(("k_pyr_l0", "void k_describe")):
             print(f"{(s - base) / 1e3:9.1f} .. {(e - base) / 1e3:9.1f} us  ({(e - s) / 1e3:7.1f})  {name}")
 
 
 if __name__ == "__main__":
     a = sys.argv[1] if len(sys.argv) > 1 else "pinned"
-    summarise(a) if os.path.isdir(a) else run(a)
+    summarise(a) if os.path.isdir(a) else run(a, int(sys.argv[2]) if len(sys.argv) > 2 else 256)
