@@ -301,7 +301,10 @@ def main():
     # together (a lone SystemExit would leave its peers blocked in the next barrier until the driver's timeout), and rank 0
     # prints what each device produced, so that a slow or failing device can be told from a slow collective
     mdev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")   # the few-byte bookkeeping exchanges
-    mine = torch.tensor([float(status.max()), n_kp], dtype=torch.float64, device=mdev)
+    smax = float(status.max())
+    if os.environ.get("ORBX_BENCH_INJECT_FAILURE") == str(rank):   # test hook: this rank reports a failed extraction (tests/test_sharding_gpu.py)
+        smax = 7.0
+    mine = torch.tensor([smax, n_kp], dtype=torch.float64, device=mdev)
     per_rank = [mine.clone() for _ in range(world)]
     if world > 1:
         dist.all_gather(per_rank, mine)

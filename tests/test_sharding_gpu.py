@@ -121,3 +121,21 @@ def test_bench_two_rank_line_carries_per_rank_fields():
     assert len(j["per_rank_ms_per_step"]) == 2 and all(0 < t <= j["ms_per_step"] * 1.001 for t in j["per_rank_ms_per_step"])
     assert j["gather_ms_per_step"] > 0 and j["gather_bytes_per_rank_per_step"] > 8 * 1000 * 60
     assert j["value"] == pytest.approx(2 * 8 * 2 / (j["ms_per_step"] * 2 / 1e3), rel=1e-2)
+
+
+def test_bench_failing_rank_takes_every_rank_down():
+    """a rank whose extraction reports a non-zero status must not leave its peers in a barrier until the driver's timeout: every rank
+    exits with code 3 after rank 0 has printed the per-rank status; the failure is injected on rank 1"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ORBX_BENCH_SHARE_GPU0="1", ORBX_BENCH_INJECT_FAILURE="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--batch", "8",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert p.returncode != 0
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, p.stdout[-2000:]
+    j = json.loads(line[0])
+    assert j["per_rank_status"] == [0, 7] and "error" in j and len(j["per_rank_keypoints"]) == 2
+    assert "value" not in j          # no throughput line from a failed run
