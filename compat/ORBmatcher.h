@@ -227,6 +227,55 @@ public:
         return n;
     }
 
+    // ---- the loop around the call above as ONE device round trip: LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:375-430)
+    // searches the current keyframe against each covisible neighbour and turns the matches into MapPoints before the next search.
+    //     ORBmatcher::TriangulationBatch batch(pKF1, vpNeighKFs);                  // in front of the loop: all Hamming distances
+    //     ... in the loop, in place of matcher.SearchForTriangulation(pKF1, pKF2, F12, vMatchedIndices, false):
+    //     batch.Search(matcher, i, F12, vMatchedIndices, false);                    // neighbour i = vpNeighKFs[i]
+    // Search reads the MapPoint assignments of both keyframes when it is called, as the reference does (:929-932, 960-963), so
+    // the points the loop has created since take part exactly as in the unbatched loop; a neighbour the loop skips is never selected.
+    class TriangulationBatch {
+    public:
+        TriangulationBatch(KeyFrame *pKF1, const std::vector<KeyFrame *> &vpNeighKFs) : kf1_(pKF1), kfs_(vpNeighKFs), b_(NULL) {
+            const std::vector<MapPoint *> vp1 = pKF1->GetMapPointMatches();
+            KeyFrameArrays a1(pKF1, vp1, false);
+            std::vector<KeyFrameArrays> a2;
+            a2.reserve(kfs_.size());
+            for (size_t k = 0; k < kfs_.size(); ++k) a2.push_back(KeyFrameArrays(kfs_[k], kfs_[k]->GetMapPointMatches(), false));
+            std::vector<orbx_keyframe_view> v2(kfs_.size());
+            std::vector<const orbx_keyframe_view *> p2(kfs_.size());
+            for (size_t k = 0; k < kfs_.size(); ++k) { v2[k] = a2[k].View(); p2[k] = &v2[k]; }
+            const orbx_keyframe_view v1 = a1.View();
+            Check(orbx_triangulation_batch_create(Handle(), &v1, (int)kfs_.size(), p2.data(), &b_));
+        }
+        ~TriangulationBatch() { orbx_triangulation_batch_destroy(b_); }
+        int Search(ORBmatcher &m, int i, cv::Mat F12, std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo) {
+            KeyFrame *pKF2 = kfs_[i];
+            const cv::Mat C2 = pKF2->GetRotation() * kf1_->GetCameraCenter() + pKF2->GetTranslation();   // epipole (:892-898)
+            const float invz = 1.0f / C2.at<float>(2);
+            const float ex = pKF2->fx * C2.at<float>(0) * invz + pKF2->cx, ey = pKF2->fy * C2.at<float>(1) * invz + pKF2->cy;
+            const std::vector<MapPoint *> vp1 = kf1_->GetMapPointMatches(), vp2 = pKF2->GetMapPointMatches();   // the assignments NOW
+            KeyFrameArrays a1(kf1_, vp1, false), a2(pKF2, vp2, false);
+            orbx_keyframe_view v1 = a1.View(), v2 = a2.View();
+            float F[9];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) F[3 * r + c] = F12.at<float>(r, c);
+            std::vector<int32_t> m12(std::max(kf1_->N, 1), -1);
+            int n = 0;
+            Check(orbx_triangulation_batch_select(b_, i, &v1, &v2, F, ex, ey, bOnlyStereo ? 1 : 0, m.mbCheckOrientation ? 1 : 0, m12.data(), &n));
+            vMatchedPairs.clear();
+            vMatchedPairs.reserve(n);
+            for (int j = 0; j < kf1_->N; ++j)
+                if (m12[j] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)j, (size_t)m12[j]));
+            return n;
+        }
+    private:
+        TriangulationBatch(const TriangulationBatch &);
+        TriangulationBatch &operator=(const TriangulationBatch &);
+        KeyFrame *kf1_;
+        std::vector<KeyFrame *> kfs_;
+        orbx_triangulation_batch *b_;
+    };
+
     // ---- include/ORBmatcher.h:184 -- src/ORBmatcher.cc:1433-1690, caller LoopClosing::ComputeSim3
     int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12,
                      const cv::Mat &t12, const float th) {

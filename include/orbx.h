@@ -263,6 +263,18 @@ orbx_status orbx_search_by_bow_keyframes(orbx_handle *h, const orbx_keyframe_vie
 orbx_status orbx_search_for_triangulation(orbx_handle *h, const orbx_keyframe_view *kf1, const orbx_keyframe_view *kf2,
                                           const float *F12, float ex, float ey, int only_stereo, int check_orientation,
                                           int32_t *matches12, int *nmatches);
+/* The loop of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:375-430) calls SearchForTriangulation for the current keyframe
+ * against each covisible neighbour and creates MapPoints for the matches before it goes on to the next neighbour.  The Hamming
+ * distances depend on descriptors and feature vectors only: _create computes them for ALL neighbours in one device round trip;
+ * _select runs the reference's selection for neighbour k on the host with the has_map_point flags the views carry WHEN IT IS
+ * CALLED (same keyframes, same feature counts as at _create): the matches of K single calls for one ~60 us round trip. */
+typedef struct orbx_triangulation_batch orbx_triangulation_batch;
+orbx_status orbx_triangulation_batch_create(orbx_handle *h, const orbx_keyframe_view *kf1, int nproblems,
+                                            const orbx_keyframe_view *const *kf2, orbx_triangulation_batch **out);
+orbx_status orbx_triangulation_batch_select(const orbx_triangulation_batch *b, int k, const orbx_keyframe_view *kf1,
+                                            const orbx_keyframe_view *kf2, const float *F12, float epipole_x, float epipole_y,
+                                            int only_stereo, int check_orientation, int32_t *matches12, int *nmatches);
+void orbx_triangulation_batch_destroy(orbx_triangulation_batch *b);
 
 /* ---- projection-guided back-end policies.  The pose algebra in front of them (cv::Mat products, cv::norm,
  * MapPoint::PredictScale: OpenCV / libm code) stays in the maintainer's shim, which IS the reference's code; the entry

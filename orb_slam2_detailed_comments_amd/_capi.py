@@ -90,7 +90,7 @@ SYMBOLS = [
     "orbx_grid_create", "orbx_grid_destroy", "orbx_grid_query", "orbx_three_maxima",
     "orbx_search_for_initialization", "orbx_stereo_match", "orbx_search_by_projection_frame",
     "orbx_search_by_projection_mappoints", "orbx_set_input_format", "orbx_search_by_bow_keyframe_frame",
-    "orbx_search_by_bow_keyframes", "orbx_search_for_triangulation", "orbx_fuse", "orbx_fuse_sim3", "orbx_fuse_batch", "orbx_fuse_sim3_batch",
+    "orbx_search_by_bow_keyframes", "orbx_search_for_triangulation", "orbx_triangulation_batch_create", "orbx_triangulation_batch_select", "orbx_triangulation_batch_destroy", "orbx_fuse", "orbx_fuse_sim3", "orbx_fuse_batch", "orbx_fuse_sim3_batch",
     "orbx_search_by_projection_sim3", "orbx_search_by_sim3", "orbx_search_by_projection_keyframe",
     "orbx_stereo_match_batch_device", "orbx_host_alloc", "orbx_host_free", "orbx_set_rectification", "orbx_undistort_keypoints_device",
     "orbx_grid_build_device", "orbx_gated_candidates",
@@ -169,6 +169,11 @@ def lib():
     L.orbx_search_for_triangulation.restype = i32
     L.orbx_search_for_triangulation.argtypes = [vp, C.POINTER(KeyFrameView), C.POINTER(KeyFrameView), vp, f32, f32, i32,
                                                 i32, vp, C.POINTER(i32)]
+    L.orbx_triangulation_batch_create.restype = i32
+    L.orbx_triangulation_batch_create.argtypes = [vp, C.POINTER(KeyFrameView), i32, vp, C.POINTER(vp)]
+    L.orbx_triangulation_batch_select.restype = i32
+    L.orbx_triangulation_batch_select.argtypes = [vp, i32, C.POINTER(KeyFrameView), C.POINTER(KeyFrameView), vp, f32, f32, i32, i32, vp, C.POINTER(i32)]
+    L.orbx_triangulation_batch_destroy.restype = None; L.orbx_triangulation_batch_destroy.argtypes = [vp]
     PT, TV = C.POINTER(ProjectedPoints), C.POINTER(TargetView)
     L.orbx_fuse.restype = i32; L.orbx_fuse.argtypes = [vp, TV, PT, f32, vp, C.POINTER(i32)]
     L.orbx_fuse_sim3.restype = i32; L.orbx_fuse_sim3.argtypes = [vp, TV, PT, f32, vp, C.POINTER(i32)]

@@ -70,30 +70,39 @@ template <class F> void walk_common_nodes(const orbx_featvec_view &f1, const orb
 struct NodeBlocks {
     std::vector<size_t> off_a;            // per node a of f1: offset of its block (SIZE_MAX = no common node)
     std::vector<int> nb_a;                // per node a: number of features of f2's node
-    std::vector<uint16_t> D;
-    orbx_status build(orbx_handle *h, const uint8_t *d1, int n1, const orbx_featvec_view &f1, const uint8_t *d2, int n2,
-                      const orbx_featvec_view &f2) {
+    std::vector<uint16_t> D;              // the distances (single call) ...
+    const uint16_t *Dp = nullptr;         // ... or a view into a batch's shared download
+    // rows / column indices of this pair's blocks, appended to a (possibly shared) request: second-set feature i is row
+    // col_offset + i of the uploaded descriptor block, distances start at `total` of the shared output
+    void plan(const orbx_featvec_view &f1, const orbx_featvec_view &f2, uint32_t col_offset, std::vector<DDistRow> &rows,
+              std::vector<uint32_t> &cols, size_t &total) {
         off_a.assign((size_t)std::max(f1.n_nodes, 0), (size_t)-1);
         nb_a.assign((size_t)std::max(f1.n_nodes, 0), 0);
-        std::vector<DDistRow> rows;
-        std::vector<uint32_t> cols;
-        size_t total = 0;
         walk_common_nodes(f1, f2, [&](int a, int b) {
             const int na = f1.begin[a + 1] - f1.begin[a], nb = f2.begin[b + 1] - f2.begin[b];
             if (na <= 0 || nb <= 0) return;
             off_a[(size_t)a] = total; nb_a[(size_t)a] = nb;
             const uint32_t cb = (uint32_t)cols.size();
-            for (int j = f2.begin[b]; j < f2.begin[b + 1]; ++j) cols.push_back(f2.index[j]);
+            for (int j = f2.begin[b]; j < f2.begin[b + 1]; ++j) cols.push_back(col_offset + f2.index[j]);
             for (int i = f1.begin[a]; i < f1.begin[a + 1]; ++i) {
                 DDistRow r; r.q = f1.index[i]; r.col_begin = cb; r.ncol = (uint32_t)nb; r.out_off = (uint32_t)total;
                 rows.push_back(r);
                 total += (size_t)nb;
             }
         });
-        if (total > 0xffffffffull) return orbx_fail(ORBX_UNSUPPORTED, "too many descriptor pairs under common vocabulary nodes");
-        return orbx_block_distances(h, d1, n1, d2, n2, rows, cols, total, D);
     }
-    const uint16_t *row(int a, int i_in_node) const { return D.data() + off_a[(size_t)a] + (size_t)i_in_node * (size_t)nb_a[(size_t)a]; }
+    orbx_status build(orbx_handle *h, const uint8_t *d1, int n1, const orbx_featvec_view &f1, const uint8_t *d2, int n2,
+                      const orbx_featvec_view &f2) {
+        std::vector<DDistRow> rows;
+        std::vector<uint32_t> cols;
+        size_t total = 0;
+        plan(f1, f2, 0u, rows, cols, total);
+        if (total > 0xffffffffull) return orbx_fail(ORBX_UNSUPPORTED, "too many descriptor pairs under common vocabulary nodes");
+        const orbx_status st = orbx_block_distances(h, d1, n1, d2, n2, rows, cols, total, D);
+        Dp = D.data();
+        return st;
+    }
+    const uint16_t *row(int a, int i_in_node) const { return Dp + off_a[(size_t)a] + (size_t)i_in_node * (size_t)nb_a[(size_t)a]; }
 };
 }  // namespace
 
@@ -209,26 +218,19 @@ static bool check_dist_epipolar(const orbx_keypoint &kp1, const orbx_keypoint &k
     return (double)dsqr < 3.84 * (double)sigma2;
 }
 
-extern "C" orbx_status orbx_search_for_triangulation(orbx_handle *h, const orbx_keyframe_view *kf1,
-                                                     const orbx_keyframe_view *kf2, const float *F12, float ex, float ey,
-                                                     int only_stereo, int check_orientation, int32_t *matches12,
-                                                     int *nmatches_out) {
-    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
-    if (!kf1 || !kf2 || !F12 || kf1->n < 0 || kf2->n < 0 || !matches12 || !nmatches_out ||
-        (kf1->n > 0 && (!kf1->keys_un || !kf1->desc || !kf1->has_map_point || !kf1->u_right)) ||
-        (kf2->n > 0 && (!kf2->keys_un || !kf2->desc || !kf2->has_map_point || !kf2->u_right || !kf2->scale_factors ||
-                        !kf2->level_sigma2)))
-        return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
-    if (!featvec_ok(kf1->feat_vec, kf1->n) || !featvec_ok(kf2->feat_vec, kf2->n)) return orbx_fail(ORBX_BAD_ARGUMENT, "malformed feature vector");
-    *nmatches_out = 0;
-    for (int i = 0; i < kf1->n; ++i) matches12[i] = -1;
-    if (kf1->n == 0 || kf2->n == 0) return ORBX_OK;
+namespace {
+bool triangulation_views_ok(const orbx_keyframe_view *kf1, const orbx_keyframe_view *kf2) {
+    return kf1 && kf2 && kf1->n >= 0 && kf2->n >= 0 &&
+           !(kf1->n > 0 && (!kf1->keys_un || !kf1->desc || !kf1->has_map_point || !kf1->u_right)) &&
+           !(kf2->n > 0 && (!kf2->keys_un || !kf2->desc || !kf2->has_map_point || !kf2->u_right || !kf2->scale_factors || !kf2->level_sigma2)) &&
+           featvec_ok(kf1->feat_vec, kf1->n) && featvec_ok(kf2->feat_vec, kf2->n);
+}
+// ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:879-1087) from the merge walk on, over the distance blocks `nbk`
+void triangulation_select(bool fma_mode, const orbx_keyframe_view *kf1, const orbx_keyframe_view *kf2, const NodeBlocks &nbk,
+                          const float *F12, float ex, float ey, int only_stereo, int check_orientation, int32_t *matches12,
+                          int *nmatches_out) {
     const int n2 = kf2->n;
-    const bool fma_mode = orbx_handle_fp_mode(h) == ORBX_FP_GCC_FMA;
     const orbx_featvec_view &f1 = kf1->feat_vec, &f2 = kf2->feat_vec;
-    NodeBlocks nbk;
-    orbx_status st = nbk.build(h, kf1->desc, kf1->n, f1, kf2->desc, n2, f2);
-    if (st != ORBX_OK) return st;
     int nmatches = 0;
     RotHist hist;
     std::vector<uint8_t> matched2((size_t)n2, 0);
@@ -268,8 +270,87 @@ extern "C" orbx_status orbx_search_for_triangulation(orbx_handle *h, const orbx_
     if (check_orientation)
         hist.reject_minor([&](int i1) { matched2[matches12[i1]] = 0; matches12[i1] = -1; nmatches--; });   // fork (:1069)
     *nmatches_out = nmatches;
+}
+}  // namespace
+
+extern "C" orbx_status orbx_search_for_triangulation(orbx_handle *h, const orbx_keyframe_view *kf1,
+                                                     const orbx_keyframe_view *kf2, const float *F12, float ex, float ey,
+                                                     int only_stereo, int check_orientation, int32_t *matches12,
+                                                     int *nmatches_out) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!F12 || !matches12 || !nmatches_out || !kf1 || !kf2 || kf1->n < 0 || kf2->n < 0) return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    if (!triangulation_views_ok(kf1, kf2)) return orbx_fail(ORBX_BAD_ARGUMENT, "bad keyframe view / malformed feature vector");
+    *nmatches_out = 0;
+    for (int i = 0; i < kf1->n; ++i) matches12[i] = -1;
+    if (kf1->n == 0 || kf2->n == 0) return ORBX_OK;
+    NodeBlocks nbk;
+    orbx_status st = nbk.build(h, kf1->desc, kf1->n, kf1->feat_vec, kf2->desc, kf2->n, kf2->feat_vec);
+    if (st != ORBX_OK) return st;
+    triangulation_select(orbx_handle_fp_mode(h) == ORBX_FP_GCC_FMA, kf1, kf2, nbk, F12, ex, ey, only_stereo, check_orientation, matches12, nmatches_out);
     return ORBX_OK;
 }
+
+// Batched form for the loop of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:375-430: the current keyframe against each
+// of its 10-20 best covisible neighbours).  The Hamming distances of a pair depend on descriptors and feature vectors only, so
+// they are computed for ALL neighbours in one device round trip (orbx_triangulation_batch_create); the selection of neighbour k
+// -- which skips features that already have a MapPoint, and the loop creates MapPoints for the matches of every neighbour before
+// it searches the next -- runs on the host when the caller asks for it, with the has_map_point flags as they are THEN
+// (orbx_triangulation_batch_select): the same matches as K single calls, with one ~60 us round trip instead of K.
+struct orbx_triangulation_batch {
+    bool fma_mode = false;
+    int n1 = 0;
+    std::vector<int> n2;
+    std::vector<NodeBlocks> blocks;   // per neighbour: views into D
+    std::vector<uint16_t> D;
+};
+extern "C" orbx_status orbx_triangulation_batch_create(orbx_handle *h, const orbx_keyframe_view *kf1, int nproblems,
+                                                       const orbx_keyframe_view *const *kf2, orbx_triangulation_batch **out) {
+    if (!h) return orbx_fail(ORBX_BAD_ARGUMENT, "null handle");
+    if (!out || !kf1 || nproblems < 0 || (nproblems > 0 && !kf2)) return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    *out = nullptr;
+    for (int k = 0; k < nproblems; ++k)
+        if (!triangulation_views_ok(kf1, kf2[k])) return orbx_fail(ORBX_BAD_ARGUMENT, "bad keyframe view / malformed feature vector");
+    orbx_triangulation_batch *b = new orbx_triangulation_batch();
+    b->fma_mode = orbx_handle_fp_mode(h) == ORBX_FP_GCC_FMA;
+    b->n1 = kf1->n;
+    b->n2.resize((size_t)nproblems);
+    b->blocks.resize((size_t)nproblems);
+    // one request: the neighbours' descriptors back to back, every neighbour's blocks appended to the same row / column lists
+    std::vector<DDistRow> rows;
+    std::vector<uint32_t> cols;
+    std::vector<uint8_t> d2;
+    size_t total = 0, nd2 = 0;
+    for (int k = 0; k < nproblems; ++k) nd2 += (size_t)kf2[k]->n;
+    d2.resize(nd2 * 32);
+    uint32_t off = 0;
+    for (int k = 0; k < nproblems; ++k) {
+        b->n2[(size_t)k] = kf2[k]->n;
+        if (kf2[k]->n > 0) memcpy(d2.data() + (size_t)off * 32, kf2[k]->desc, (size_t)kf2[k]->n * 32);
+        if (kf1->n > 0 && kf2[k]->n > 0) b->blocks[(size_t)k].plan(kf1->feat_vec, kf2[k]->feat_vec, off, rows, cols, total);
+        off += (uint32_t)kf2[k]->n;
+    }
+    if (total > 0xffffffffull) { delete b; return orbx_fail(ORBX_UNSUPPORTED, "too many descriptor pairs under common vocabulary nodes"); }
+    if (total > 0) {
+        const orbx_status st = orbx_block_distances(h, kf1->desc, kf1->n, d2.data(), (int)nd2, rows, cols, total, b->D);
+        if (st != ORBX_OK) { delete b; return st; }
+    }
+    for (NodeBlocks &nb : b->blocks) nb.Dp = b->D.data();
+    *out = b;
+    return ORBX_OK;
+}
+extern "C" orbx_status orbx_triangulation_batch_select(const orbx_triangulation_batch *b, int k, const orbx_keyframe_view *kf1,
+                                                       const orbx_keyframe_view *kf2, const float *F12, float ex, float ey,
+                                                       int only_stereo, int check_orientation, int32_t *matches12, int *nmatches_out) {
+    if (!b || k < 0 || k >= (int)b->blocks.size() || !F12 || !matches12 || !nmatches_out) return orbx_fail(ORBX_BAD_ARGUMENT, "bad argument");
+    if (!triangulation_views_ok(kf1, kf2) || kf1->n != b->n1 || kf2->n != b->n2[(size_t)k])
+        return orbx_fail(ORBX_BAD_ARGUMENT, "the views of a selection must describe the keyframes the batch was created for");
+    *nmatches_out = 0;
+    for (int i = 0; i < kf1->n; ++i) matches12[i] = -1;
+    if (kf1->n == 0 || kf2->n == 0) return ORBX_OK;
+    triangulation_select(b->fma_mode, kf1, kf2, b->blocks[(size_t)k], F12, ex, ey, only_stereo, check_orientation, matches12, nmatches_out);
+    return ORBX_OK;
+}
+extern "C" void orbx_triangulation_batch_destroy(orbx_triangulation_batch *b) { delete b; }
 
 // ================================================================================================================
 // Projection-guided back-end policies (second half): Fuse (both overloads),

@@ -174,6 +174,12 @@ class ORBmatcher:
                                                     ptr(out), C.byref(n)))
         return n.value, out[:v1.n].copy()
 
+    def TriangulationBatch(self, kf1, kf2_list):
+        """the loop of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:375-430) as one device round trip: the distances of
+        kf1 against every neighbour now, the selection per neighbour later (.select(k, ...)) with the has_map_point flags of that
+        moment.  Use as a context manager or call .close()."""
+        return _TriangulationBatch(self, kf1, kf2_list)
+
     # ---- projection-guided back-end policies (src/ORBmatcher.cc:1100-1280, 1282-1430, 415-560, 1433-1690, 1873-2020)
     @staticmethod
     def _target(t, keep):
@@ -285,3 +291,34 @@ class ORBmatcher:
         elif max3 < np.float32(0.1) * np.float32(max1):
             ind3 = -1
         return ind1, ind2, ind3
+
+
+class _TriangulationBatch:
+    def __init__(self, m, kf1, kf2_list):
+        import ctypes as C
+        self._m, self._keep = m, []
+        v1 = m._kf_view(kf1, self._keep)
+        v2 = [m._kf_view(k, self._keep) for k in kf2_list]
+        arr = (C.c_void_p * max(len(v2), 1))(*[C.addressof(v) for v in v2])
+        self._b = C.c_void_p(0)
+        check(m._L.orbx_triangulation_batch_create(m._ex.handle, C.byref(v1), len(v2), arr, C.byref(self._b)))
+        self.n = len(v2)
+
+    def select(self, k, kf1_now, kf2_now, F12, epipole, bOnlyStereo=False):
+        """SearchForTriangulation(kf1, kf2[k]) on the batch's distances; kf1_now / kf2_now carry the CURRENT has_map_point flags"""
+        import ctypes as C
+        keep = []
+        v1, v2 = self._m._kf_view(kf1_now, keep), self._m._kf_view(kf2_now, keep)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        out = np.full(max(v1.n, 1), -1, np.int32); n = C.c_int(0)
+        check(self._m._L.orbx_triangulation_batch_select(self._b, int(k), C.byref(v1), C.byref(v2), ptr(F), float(epipole[0]), float(epipole[1]),
+                                                         int(bOnlyStereo), int(self._m.mbCheckOrientation), ptr(out), C.byref(n)))
+        return n.value, out[:v1.n].copy()
+
+    def close(self):
+        if self._b:
+            self._m._L.orbx_triangulation_batch_destroy(self._b); self._b = None
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+    def __del__(self): self.close()

@@ -19,5 +19,7 @@ int use(Frame &F, Frame &F2, KeyFrame *k1, KeyFrame *k2, std::vector<MapPoint *>
     n += m.Fuse(k1, S, mps, 4.f, mps);
     std::vector<KeyFrame *> kfs(2, k1);
     n += m.FuseBatch(kfs, mps, 3.f);
+    ORBmatcher::TriangulationBatch tb(k1, kfs);
+    n += tb.Search(m, 1, F12, pairs, false);
     return n + ORBmatcher::TH_LOW + ORBmatcher::TH_HIGH + ORBmatcher::HISTO_LENGTH;
 }

@@ -180,6 +180,47 @@ def test_gpu_bow_policies_equal_oracle(ratio, ori):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fp", [0, 1])
+def test_gpu_triangulation_batch_equals_the_loop_of_single_calls(fp):
+    """orbx_triangulation_batch_*: the CreateNewMapPoints loop (src/LocalMapping.cc:375-430) -- SearchForTriangulation of the current
+    keyframe against each neighbour, MapPoints created for (some of) the matches before the next neighbour is searched -- with the
+    distances of all neighbours from ONE device call.  Neighbour by neighbour the same matches as the single call and as the
+    oracle, with kf1's has_map_point flags fed back between the searches exactly as the loop does."""
+    from orb_slam2_detailed_comments_amd import ORBextractor, ORBmatcher, OrbxError, synth
+    frames = synth.stream(640, 480, 4, stream_id=33)
+    ex = ORBextractor(1000, max_batch=4, fp_mode=fp)
+    res = ex.extract_batch(frames)
+    rng = np.random.default_rng(5)
+    sf = ex.GetScaleFactors()
+    mk = lambda k, d, p: dict(keys_un=k, desc=d, has_map_point=(rng.uniform(size=len(k)) < p).astype(np.uint8),
+                              u_right=np.where(rng.uniform(size=len(k)) < 0.4, k["x"] - 5, -1).astype(np.float32),
+                              feat_vec=make_featvec(d, bits=4, shuffle_rng=rng), scale_factors=sf, level_sigma2=(sf * sf).astype(np.float32))
+    kf1 = mk(*res[0], 0.5)
+    nbrs = [mk(*res[1], 0.5), mk(res[2][0][:400], res[2][1][:400], 0.3), mk(*res[3], 0.6), mk(res[1][0][:0], res[1][1][:0], 0.5)]
+    Fs = [np.array([[0, 0, 2.0 * (i + 1)], [0, 0, -3.0 * (i + 1)], [-2.0 * (i + 1), 3.0 * (i + 1), 0]], np.float32) for i in range(len(nbrs))]
+    epi = (-1000.0, -700.0)
+    m = ORBmatcher(0.6, True, extractor=ex)
+    total = 0
+    with m.TriangulationBatch(kf1, nbrs) as tb:
+        cur = dict(kf1, has_map_point=kf1["has_map_point"].copy())
+        for k, (kf2, F12) in enumerate(zip(nbrs, Fs)):
+            n, m12 = tb.select(k, cur, kf2, F12, epi, False)
+            n1, s12 = m.SearchForTriangulation(cur, kf2, F12, epi, False)
+            assert n == n1 and np.array_equal(m12, s12), f"neighbour {k}: batch differs from the single call"
+            if len(kf2["keys_un"]):
+                on, om12 = oracle.search_for_triangulation(cur, kf2, F12, epi, False, True, fp)
+                assert n == on and np.array_equal(m12, om12), f"neighbour {k}: batch differs from the oracle"
+            # the loop triangulates the matches and gives (most of) them MapPoints: the next search must not see those features
+            got = np.nonzero(m12 >= 0)[0]
+            made = got[rng.uniform(size=len(got)) < 0.8]
+            cur = dict(cur, has_map_point=cur["has_map_point"].copy()); cur["has_map_point"][made] = 1
+            total += n
+        with pytest.raises(OrbxError):
+            tb.select(1, cur, nbrs[0], Fs[0], epi)          # the views of a selection describe the keyframes of the batch
+    assert total > 10
+
+
+@pytest.mark.gpu
 def test_gpu_bow_policies_empty_and_malformed():
     from orb_slam2_detailed_comments_amd import ORBextractor, ORBmatcher, OrbxError
     rng = np.random.default_rng(9)

@@ -130,6 +130,28 @@ def main():
         lambda: m.SearchForTriangulation(kf1, kf2, F12, (-1000.0, -700.0), False),
         lambda: oracle.search_for_triangulation(kf1, kf2, F12, (-1000.0, -700.0), False, True, 0))
 
+    # the CreateNewMapPoints loop: K neighbours, distances from one device call, selection per neighbour (us per neighbour)
+    # (C ABI with the views marshalled once, as for the Fuse batches)
+    for K in (8, 20):
+        keep = []
+        v1 = m._kf_view(kf1, keep); v2s = [m._kf_view(kf2, keep) for _ in range(K)]
+        arr = (C.c_void_p * K)(*[C.addressof(v) for v in v2s])
+        Fc = np.ascontiguousarray(F12, np.float32).reshape(9); out = np.full(max(v1.n, 1), -1, np.int32); nn = C.c_int(0)
+        def tri_batch():
+            b = C.c_void_p(0)
+            _capi.check(Lc.orbx_triangulation_batch_create(ex.handle, C.byref(v1), K, arr, C.byref(b)))
+            for k in range(K):
+                _capi.check(Lc.orbx_triangulation_batch_select(b, k, C.byref(v1), C.byref(v2s[k]), _capi.ptr(Fc), -1000.0, -700.0, 0, 1, _capi.ptr(out), C.byref(nn)))
+            Lc.orbx_triangulation_batch_destroy(b)
+        def tri_single():
+            for k in range(K):
+                _capi.check(Lc.orbx_search_for_triangulation(ex.handle, C.byref(v1), C.byref(v2s[k]), _capi.ptr(Fc), -1000.0, -700.0, 0, 1, _capi.ptr(out), C.byref(nn)))
+        g, g1 = bench(tri_batch, 10), bench(tri_single, 10)
+        c = bench(lambda: [oracle.search_for_triangulation(kf1, kf2, F12, (-1000.0, -700.0), False, True, 0) for _ in range(K)], 3)
+        rows.append(dict(entry_point=f"orbx_triangulation_batch K={K}", reference="LocalMapping.cc:375-430 loop", gpu_us=round(g / K, 1),
+                         single_calls_us=round(g1 / K, 1), cpu_oracle_us=round(c / K, 1), ratio=round(c / g, 2), problems=K))
+        print(f"{'orbx_triangulation_batch K=' + str(K):40s} {'us per neighbour (C ABI)':38s} GPU {g / K:9.1f} us   CPU oracle {c / K:10.1f} us   x{c / g:6.2f}   (K single calls at the C ABI: {g1 / K:.1f} us each)", flush=True)
+
     # ---- ComputeStereoMatches (KITTI size, host-buffer entry point) and brute-force best / second
     L, R = synth.stereo_pair(1241, 376, stream_id=6)
     exL, exR = ORBextractor(2000), ORBextractor(2000)
