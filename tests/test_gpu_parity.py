@@ -147,6 +147,29 @@ def test_row_stride_and_chunking_and_resize_of_handle():
     assert_frame_equal(ex(frames[1]), orc.extract(frames[1]), "back to the first geometry")
 
 
+def test_pipelined_host_call_from_page_locked_memory():
+    """orbx_extract_batch from page-locked buffers in and out: uploads and downloads take turns on one copy stream while a chunk
+    computes (round 3); many chunks, a partial last chunk, a longer call after a shorter one on the same handle (the landing buffer
+    of the per-frame counts / status grows), strided frames -- every frame equal to the oracle, counts in the caller's array"""
+    import ctypes as C
+    L = _capi.lib()
+    W, H = 320, 240
+    ex = ORBextractor(400, max_batch=3)
+    orc = oracle.OracleExtractor(400)
+    cap = ex.max_keypoints(W, H)
+    for n in (4, 11):
+        frames = synth.stream(W, H, n, stream_id=60 + n)
+        keep = [_capi.PinnedArray((n, H, W + 32)), _capi.PinnedArray((n, cap), _capi.KP_DTYPE), _capi.PinnedArray((n, cap, 32)),
+                _capi.PinnedArray((n,), np.int32)]
+        img, kps, desc, cnt = (k.array for k in keep)
+        img[...] = 0; img[:, :, :W] = frames; cnt[...] = -7
+        _capi.check(L.orbx_extract_batch(ex.handle, n, _capi.ptr(img), W, H, W + 32, (W + 32) * H, _capi.ptr(kps), _capi.ptr(desc), _capi.ptr(cnt), cap))
+        for f in range(n):
+            on, ok, od = orc.extract(frames[f])
+            assert cnt[f] == on, f"count of frame {f} of {n}"
+            assert kps[f, :on].tobytes() == ok.tobytes() and np.array_equal(desc[f, :on], od), f"frame {f} of {n}"
+
+
 def test_errors_and_capacity():
     ex = ORBextractor(300)
     with pytest.raises(OrbxError) as e:
