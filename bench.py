@@ -116,8 +116,10 @@ def cpu_baseline(frames, right, nfeatures, stereo, mb, mbf, budget_s=20.0):
         flags = oracle.orb_oracle.NATIVE_FLAGS
     except Exception:
         os.environ.pop("ORB_ORACLE_LIB", None)
+    cores = None
     try:
-        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[-1]})   # taskset -c <core>
+        cores = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, {sorted(cores)[-1]})   # taskset -c <core>
         pinned = True
     except Exception:
         pinned = False
@@ -140,7 +142,32 @@ def cpu_baseline(frames, right, nfeatures, stereo, mb, mbf, budget_s=20.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
+    if pinned:
+        os.sched_setaffinity(0, cores)   # what follows (host_io) is not a one-core measurement
     return n / dt, n, pinned, flags
+
+
+def host_io_rate(L, frames, W, H, NF, cap, local_rank):
+    """secondary figure: the same extraction fed from HOST memory through orbx_extract_batch (page-locked buffers in and out, the
+    step's frames in chunks of 64: upload of chunk c+1 / download of chunk c-1 on one copy stream while chunk c computes; keypoints
+    and descriptors are written by the GPU straight into the page-locked result buffers), PCIe inclusive.  Never `value`."""
+    nh, hchunk = min(len(frames), 1024), 64
+    exh = ORBextractor(NF, 1.2, 8, 20, 7, max_batch=hchunk, device=local_rank)
+    keep = [_capi.PinnedArray((nh, H, W)), _capi.PinnedArray((nh, cap), _capi.KP_DTYPE), _capi.PinnedArray((nh, cap, 32)),
+            _capi.PinnedArray((nh,), np.int32)]
+    himg, hk, hd, hc = (k.array for k in keep)
+    himg[...] = frames[:nh]
+    hcall = lambda: _capi.check(L.orbx_extract_batch(exh.handle, nh, _capi.ptr(himg), W, H, W, W * H, _capi.ptr(hk), _capi.ptr(hd), _capi.ptr(hc), cap))
+    hcall(); hcall()
+    th = time.perf_counter()
+    for _ in range(6):
+        hcall()
+    th = (time.perf_counter() - th) / 6
+    del exh
+    return {"value": round(nh / th, 1), "unit": "frames/s", "frames_per_call": nh, "chunk": hchunk, "ms_per_call": round(th * 1e3, 3),
+            "memory": "page-locked host buffers in and out (orbx_host_alloc), extraction only",
+            "bytes_per_frame": int(W * H + cap * 60 + 4),
+            "link_GBs": round(nh / th * (W * H + cap * 60 + 4) / 1e9, 2)}
 
 
 def main():
@@ -476,26 +503,7 @@ def main():
                                              f"single-thread CPU oracle (extract{' x2 + ComputeStereoMatches' if stereo else ' + brute-force match'}), "
                                              f"{'pinned to one core' if pinned else 'not pinned'}, host has {os.cpu_count()} cores"}
         if not stereo and not args.no_host_io and world == 1:
-            # secondary figure: the same extraction fed from HOST memory through orbx_extract_batch (page-locked buffers in and out,
-            # the step's frames in chunks of 64: upload of chunk c+1 / download of chunk c-1 on one copy stream while chunk c
-            # computes), PCIe inclusive.  Never `value`.
-            nh, hchunk = min(B, 256), 64
-            exh = ORBextractor(NF, 1.2, 8, 20, 7, max_batch=hchunk, device=local_rank)
-            keep = [_capi.PinnedArray((nh, H, W)), _capi.PinnedArray((nh, cap), _capi.KP_DTYPE), _capi.PinnedArray((nh, cap, 32)),
-                    _capi.PinnedArray((nh,), np.int32)]
-            himg, hk, hd, hc = (k.array for k in keep)
-            himg[...] = frames[:nh]
-            hcall = lambda: _capi.check(L.orbx_extract_batch(exh.handle, nh, _capi.ptr(himg), W, H, W, W * H, _capi.ptr(hk), _capi.ptr(hd), _capi.ptr(hc), cap))
-            hcall(); hcall()
-            th = time.perf_counter()
-            for _ in range(4):
-                hcall()
-            th = (time.perf_counter() - th) / 4
-            out["host_io"] = {"value": round(nh / th, 1), "unit": "frames/s", "frames_per_call": nh, "chunk": hchunk, "ms_per_call": round(th * 1e3, 3),
-                              "memory": "page-locked host buffers in and out (orbx_host_alloc), extraction only",
-                              "bytes_per_frame": int(W * H + cap * 60 + 4),
-                              "link_GBs": round(nh / th * (W * H + cap * 60 + 4) / 1e9, 2)}
-            del exh
+            out["host_io"] = host_io_rate(L, frames, W, H, NF, cap, local_rank)
         if args.stages:
             for k, v in prof.items():
                 print(f"  {k:14s} {v[0] / 2:9.4f} ms/step  ({v[1] // 2} launches/step)", file=sys.stderr)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from orb_slam2_detailed_comments_amd import ORBextractor, synth, _capi
 
-N, W, H = 256, 640, 480
+N, W, H = int(os.environ.get("HOST_IO_FRAMES", "256")), 640, 480
 frames = synth.stream(W, H, 64, stream_id=100)
 frames = np.concatenate([frames] * (N // 64))
 L = _capi.lib()
