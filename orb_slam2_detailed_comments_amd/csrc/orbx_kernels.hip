@@ -1255,6 +1255,9 @@ __constant__ int4 c_pattern_lane[64];
 // row it covers, as byte weights for v_dot4_u32_u8: [0..4] = u + 16 inside the disc (|u| <= umax[|v|]) else 0, [5..9] = 1
 // inside the disc else 0.  m10 = sum(u * I) = dot(I, u + 16) - 16 * dot(I, 1), m01 = v * dot(I, 1): exact integers.
 __constant__ uint32_t c_orient_w[64][12];
+// B operands of the row pass on the matrix pipe (DS_MFMA): the banded 7-tap kernel, output column tile j of 16:
+// entry [j][lane][.] = the 16 bytes B[k = 16 (lane >> 4) + s][n = lane & 15] = K7[k - (16 j + n)] (0 outside the band)
+__constant__ uint32_t c_blur_b[3][64][4];
 
 // The 7x7 Gaussian (reference :2039-2047) is fused in: only a 43x43 neighbourhood of each keypoint is ever sampled
 // (|tap| <= 18, +3 px filter support), so each wave stages that patch of the UN-blurred level in LDS, runs the
@@ -1267,7 +1270,30 @@ __constant__ uint32_t c_orient_w[64][12];
 #define DS_R 21                 // patch radius: 18 (taps) + 3 (filter support)
 #define DS_W (2 * DS_R + 1)     // 43
 #define DS_PP 44                // LDS patch pitch in bytes (11 dwords; rows start dword-aligned in LDS)
-#define DS_HC 40                // row-pass outputs per row (37 needed, computed in groups of 4)
+#define DS_HC 40                // row-pass outputs per row (37 needed, computed in groups of 4)   [DS_COLFIRST == 0]
+#ifndef DS_COLFIRST
+#define DS_COLFIRST 1
+#endif
+// DS_COLFIRST: the separable Gaussian with the passes in the OTHER order.  The total I = sum_ij k_i k_j p[y+j][x+i] is one exact
+// integer whichever pass runs first (every partial sum <= 255 * 257 = 65535), so the result is the same bit for bit -- but with
+// the COLUMN pass done over the whole patch (v[r][c] = sum_j k_j p[r+j][c], u16), the seven values a tap needs are horizontal
+// neighbours: 14 contiguous bytes = two ds_read2_b32 from a dword-aligned address instead of seven ds_read_u16 at a 80-byte
+// stride, folded by four v_dot2_u32_u16 against weights chosen by the parity of the tap's column.  The tap reads are what the
+// LDS pipe of this kernel is busy with (56 per lane, 60 % of its active cycles bank conflicts).
+#ifndef DS_ALIAS
+#define DS_ALIAS 1
+#endif
+// DS_MFMA (with DS_COLFIRST's tap code): the first pass is the ROW pass again, but on the matrix pipe, which this kernel
+// leaves idle while its vector pipe is the busiest port: H = (P - 128) x B + 128 * 257 with P the patch rows as int8 (x ^ 0x80),
+// B the banded kernel (c_blur_b), as nine v_mfma_i32_16x16x64_i8 (3 row tiles x 3 column tiles, K = 64 patch columns at once),
+// exact in int32.  The accumulator layout hands every lane FOUR CONSECUTIVE ROWS of one column, so the results are stored
+// transposed for free -- HT[c][r], one ds_write_b64 per tile -- and the seven values a tap needs (vertical neighbours) are
+// contiguous again: the same 16-byte window + four v_dot2 as the column-first form.  ~45 vector instructions instead of ~150.
+#ifndef DS_MFMA
+#define DS_MFMA 1
+#endif
+#define DS_VC 44                // columns of v (43 needed: taps -18..18, +-3)
+#define DS_VR 40                // rows of v computed (37 needed: five lane groups of 8)
 #ifndef DS_WPB
 #define DS_WPB 1   // waves (= keypoints) per block.  Nothing is shared between the waves of a block; one-wave blocks let the
                    // dispatcher place every wave as soon as any SIMD has room: 282 us against 299 (4 waves) and 372 (8)
@@ -1289,6 +1315,22 @@ __constant__ uint32_t c_orient_w[64][12];
 // LDS round trips, and resident waves are what hides them.)
 // FPM (fp_mode) is a template constant: as a run-time value it costs a scalar branch and both code paths in each of the 8 taps
 typedef const __attribute__((address_space(3))) uint16_t *orbx_lds_u16p;
+typedef const __attribute__((address_space(3))) uint32_t *orbx_lds_u32p;
+// I = sum_i k_i v[r][c + i], i = 0..6, for the u16 element at LDS byte address `adr` (DS_COLFIRST): the 8 elements of the
+// dword-aligned 16-byte window around them, against the weights shifted by the parity of c
+__device__ __forceinline__ uint32_t orbx_ds_tap(uint32_t adr) {
+    const bool odd = (adr & 2u) != 0;
+    const orbx_lds_u32p wp = (orbx_lds_u32p)(uintptr_t)(adr & ~3u);
+    const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3];
+    const uint32_t w0 = odd ? (18u << 16) : (18u | (34u << 16)), w1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16)),
+                   w2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), w3 = odd ? (34u | (18u << 16)) : 18u;
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    uint32_t I = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d0), __builtin_bit_cast(u16x2, w0), 0u, false);
+    I = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d1), __builtin_bit_cast(u16x2, w1), I, false);
+    I = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d2), __builtin_bit_cast(u16x2, w2), I, false);
+    I = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d3), __builtin_bit_cast(u16x2, w3), I, false);
+    return I;   // < 2^24.01
+}
 template <int FPM>
 __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
                                                   const uint32_t *__restrict__ lvl_kp,
@@ -1301,8 +1343,15 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
 #ifndef ORBX_TIMING_KNOBS
     dbg_stop = 0;
 #endif
+#if DS_COLFIRST && DS_ALIAS
+    // v OVER the patch: the column pass holds every patch row it needs in registers before its first store (a wave's LDS
+    // instructions execute in order, and one wave owns the buffers), and nothing reads the patch afterwards -- 3.5 KB of LDS per
+    // wave instead of 5.4
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[DS_WPB][DS_VR * DS_VC];
+#else
     __shared__ uint32_t s_patch[DS_WPB][DS_W * DS_PP / 4 + 4];
-    __shared__ __attribute__((aligned(16))) uint16_t s_h[DS_WPB][DS_W * DS_HC];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[DS_WPB][DS_COLFIRST ? DS_VR * DS_VC : DS_W * DS_HC];
+#endif
     // one wave per keypoint, waves indexed by dense OUTPUT position (level-major order of operator(), :2066-2082).
     // The wave index is wave-uniform (which the compiler cannot see): with it scalar, the level search and the position
     // load run on the scalar unit.
@@ -1334,7 +1383,11 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
         if (total > cap) atomicMax(&status[f], (int)ORBX_CAPACITY);
     }
     if (oi >= min(total, cap) || dbg_stop == 4) return;
+#if DS_COLFIRST && DS_ALIAS
+    uint32_t *patch = (uint32_t *)s_h[wv_id];
+#else
     uint32_t *patch = s_patch[wv_id];
+#endif
     uint16_t *hrow = s_h[wv_id];
     const uint32_t pos = lvl_kp[(long long)f * g.kp_total + slot];
     const int4 pat = c_pattern_lane[lane];
@@ -1403,6 +1456,64 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
         if (dbg_stop == 2) return;
         // ---- row pass: h[r][c] for patch columns c+3 (c = 0..36 used); 4 outputs per item from 3 aligned dwords via
         // v_alignbyte + v_dot4_u32_u8 with the packed 8-bit kernel {18,34,49,55 | 49,34,18,0}
+#if DS_COLFIRST && DS_MFMA
+        {
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const int m = lane & 15, gq = lane >> 4;
+            i32x4 A[3], Bm[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {   // A[t]: patch row 16 t + m, bytes 16 gq .. + 15 (rows >= 43 / bytes >= 43: don't-care, zero weights or unused rows)
+                const uint32_t *ap = patch + (16 * t + m) * (DS_PP / 4) + 4 * gq;
+                A[t][0] = (int)(ap[0] ^ 0x80808080u); A[t][1] = (int)(ap[1] ^ 0x80808080u);
+                A[t][2] = (int)(ap[2] ^ 0x80808080u); A[t][3] = (int)(ap[3] ^ 0x80808080u);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint4 b4 = *(const uint4 *)&c_blur_b[j][lane][0];
+                Bm[j][0] = (int)b4.x; Bm[j][1] = (int)b4.y; Bm[j][2] = (int)b4.z; Bm[j][3] = (int)b4.w;
+            }
+            const i32x4 c0 = {128 * 257, 128 * 257, 128 * 257, 128 * 257};
+            uint32_t *vo = (uint32_t *)hrow + m * (DS_VC / 2) + 2 * gq;   // HT[c = 16 j + m][r = 16 t + 4 gq ..]: u16 index c * 44 + r
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const i32x4 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], Bm[j], c0, 0, 0, 0);
+                    // columns c < 37 and rows r < 44 exist in HT
+                    if ((j < 2 || m < DS_W - 6 - 32) && (t < 2 || gq < 3))
+                        *(uint2 *)(vo + (16 * j) * (DS_VC / 2) + 8 * t) =
+                            make_uint2((uint32_t)acc[0] | ((uint32_t)acc[1] << 16), (uint32_t)acc[2] | ((uint32_t)acc[3] << 16));
+                }
+            }
+        }
+#elif DS_COLFIRST
+        // ---- column pass over the whole patch: lane = (dword column cg of 11, row group seg of 5), 8 output rows from 14 patch
+        // rows held in registers as u16 pairs (v_perm), the filter as packed 16-bit multiply-adds (sums <= 65535)
+        {
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            const int seg = (lane * 373) >> 12, cg = lane - 11 * seg;   // lane / 11, lane % 11
+            if (seg < 5) {
+                // (the symmetric sums and the centre product as plain 32-bit operations on the pair -- no carry crosses the halves:
+                // <= 510 and <= 14025 -- which issue at the full rate; the three multiply-adds of the sums are packed 16-bit ones)
+                uint32_t pa[14], pb[14];
+#pragma unroll
+                for (int j = 0; j < 14; ++j) {
+                    const uint32_t d = patch[min(8 * seg + j, DS_W - 1) * (DS_PP / 4) + cg];
+                    pa[j] = __builtin_amdgcn_perm(0u, d, 0x0c010c00u);   // columns 4cg, 4cg+1 as u16 pair
+                    pb[j] = __builtin_amdgcn_perm(0u, d, 0x0c030c02u);   // columns 4cg+2, 4cg+3
+                }
+                const u16x2 k1 = {49, 49}, k2 = {34, 34}, k3 = {18, 18};
+                uint32_t *vo = (uint32_t *)hrow + (8 * seg) * (DS_VC / 2) + 2 * cg;
+#define DS_CP(P, r)                                                                                                          \
+    __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, P[r + 2] + P[r + 4]) * k1 +                                       \
+                                     (__builtin_bit_cast(u16x2, P[r + 1] + P[r + 5]) * k2 +                                  \
+                                      (__builtin_bit_cast(u16x2, P[r] + P[r + 6]) * k3 + __builtin_bit_cast(u16x2, __umul24(P[r + 3], 55u)))))
+#pragma unroll
+                for (int r = 0; r < 8; ++r) *(uint2 *)(vo + r * (DS_VC / 2)) = make_uint2(DS_CP(pa, r), DS_CP(pb, r));
+#undef DS_CP
+            }
+        }
+#else
         for (int i = lane; i < DS_W * (DS_HC / 8); i += 64) {
             // item = 8 consecutive outputs of one row from 4 aligned dwords: the byte-shifted middle dwords are shared
             // between the two groups of four (9 v_alignbyte + 16 v_dot4 per 8 outputs)
@@ -1427,6 +1538,7 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
             o.w = hv[6] | (hv[7] << 16);
             *(uint4 *)(hrow + r * DS_HC + 8 * q8) = o;
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1449,7 +1561,11 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
             // float form of round-half-even is the shortest.  cvRound of the rotated coordinates = adding 1.5 * 2^23
             // (round-to-nearest-even in the add, the integer lands in the low mantissa bits); the 24-bit multiply-add
             // takes those low bits as they are, the exponent bits of the column term cancel in the constant.
+#if DS_COLFIRST
+            const uint32_t cbias = (uint32_t)(2 * ((DS_R - 3) * DS_VC + (DS_R - 3))) - 0x400000u * (2u * DS_VC) - (0x4B400000u << 1);
+#else
             const uint32_t cbias = (uint32_t)(2 * ((DS_R - 3) * DS_HC + (DS_R - 3))) - 0x400000u * (2u * DS_HC) - (0x4B400000u << 1);
+#endif
             const uint32_t hbase = (uint32_t)(uintptr_t)(orbx_lds_u16p)hrow + cbias;
             float tv[8];
 #pragma unroll
@@ -1467,12 +1583,21 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
                         fx = px * a - py * b;
                     }
                     const uint32_t uy = __float_as_uint(fy + 12582912.0f), ux = __float_as_uint(fx + 12582912.0f);
+#if DS_COLFIRST
+#if DS_MFMA
+                    const uint32_t adr = __umul24(ux, 2u * DS_VC) + ((uy << 1) + hbase);   // LDS byte address of HT[ix+18][iy+18]: the tap's window starts here
+#else
+                    const uint32_t adr = __umul24(uy, 2u * DS_VC) + ((ux << 1) + hbase);   // LDS byte address of v[iy+18][ix+18]: the tap's window starts here
+#endif
+                    const uint32_t I = orbx_ds_tap(adr);
+#else
                     uint32_t adr = __umul24(uy, 2u * DS_HC) + ((ux << 1) + hbase);   // LDS byte address of h[iy+18][ix+18]
                     asm("" : "+v"(adr));   // a plain address from here on: the row offsets fold into the ds_read immediates
                     const orbx_lds_u16p hp = (orbx_lds_u16p)(uintptr_t)adr;
                     const uint32_t r0 = hp[3 * DS_HC], r1 = (uint32_t)hp[2 * DS_HC] + hp[4 * DS_HC],
                                    r2 = (uint32_t)hp[1 * DS_HC] + hp[5 * DS_HC], r3 = (uint32_t)hp[0] + hp[6 * DS_HC];
                     const uint32_t I = __umul24(55u, r0) + __umul24(49u, r1) + __umul24(34u, r2) + __umul24(18u, r3);   // < 2^24.01
+#endif
                     // I <= 2^24 converts exactly and I * 2^-16 is exact; above, the conversion's own rounding keeps it >= 256
                     tv[2 * r + s2] = __builtin_fminf(__builtin_rintf((float)I * (1.f / 65536.f)), 255.f);
                 }
@@ -1497,10 +1622,18 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
                     }
                     const int iy = (int)__builtin_rintf(fy), ix = (int)__builtin_rintf(fx);
                     // blurred pixel (x+ix, y+iy): column pass over h rows (iy+21-3 .. iy+21+3), h column ix+18
+#if DS_COLFIRST
+#if DS_MFMA
+                    const uint32_t I = orbx_ds_tap((uint32_t)(uintptr_t)(orbx_lds_u16p)hrow + 2u * (uint32_t)(__mul24(ix + DS_R - 3, DS_VC) + (iy + DS_R - 3)));
+#else
+                    const uint32_t I = orbx_ds_tap((uint32_t)(uintptr_t)(orbx_lds_u16p)hrow + 2u * (uint32_t)(__mul24(iy + DS_R - 3, DS_VC) + (ix + DS_R - 3)));
+#endif
+#else
                     const uint16_t *hp = hrow + __mul24(iy + DS_R - 3, DS_HC) + (ix + DS_R - 3);
                     const uint32_t r0 = hp[3 * DS_HC], r1 = (uint32_t)hp[2 * DS_HC] + hp[4 * DS_HC],
                                    r2 = (uint32_t)hp[1 * DS_HC] + hp[5 * DS_HC], r3 = (uint32_t)hp[0] + hp[6 * DS_HC];
                     const uint32_t I = __umul24(55u, r0) + __umul24(49u, r1) + __umul24(34u, r2) + __umul24(18u, r3);
+#endif
                     const uint32_t tie = x + ix >= wvec ? 1u : ((I >> 16) & 1u);   // half-up in the tail, half-even elsewhere
                     tval[2 * r + s2] = (int)min((I + 0x7fffu + tie) >> 16, 255u);
                 }
@@ -2369,7 +2502,18 @@ hipError_t orbx_upload_pattern() {
                 }
             }
     }
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_orient_w), w, sizeof(w));
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_orient_w), w, sizeof(w));
+    if (e != hipSuccess) return e;
+    static uint32_t bb[3][64][4];
+    memset(bb, 0, sizeof(bb));
+    const int K7[7] = {18, 34, 49, 55, 49, 34, 18};   // the 8-bit Gaussian of k_blur / k_describe
+    for (int j = 0; j < 3; ++j)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int sl = 0; sl < 16; ++sl) {
+                const int k = 16 * (lane >> 4) + sl, i = k - (16 * j + (lane & 15));
+                if (i >= 0 && i <= 6) bb[j][lane][sl >> 2] |= (uint32_t)K7[i] << (8 * (sl & 3));
+            }
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_blur_b), bb, sizeof(bb));
 }
 
 size_t orbx_quadtree_smem(int ncap, int lds_keys) {
