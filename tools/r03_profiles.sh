@@ -16,7 +16,7 @@ fi
 if [ $stage = bench ] || [ $stage = all ]; then
   python bench.py --stages > $o/r03_${tag}_bench_tum.log 2>&1; tail -1 $o/r03_${tag}_bench_tum.log | cut -c1-300
   python bench.py --batch 256 --no-cpu-baseline > $o/r03_${tag}_bench_tum_batch256.log 2>&1; tail -1 $o/r03_${tag}_bench_tum_batch256.log | cut -c1-200
-  python tools/host_io_rate.py > $o/r03_${tag}_host_io_rate.log 2>&1; cat $o/r03_${tag}_host_io_rate.log
+  python tools/host_io_rate.py > $o/r03_${tag}_host_io_rate.log 2>&1; HOST_IO_FRAMES=1024 python tools/host_io_rate.py >> $o/r03_${tag}_host_io_rate.log 2>&1; cat $o/r03_${tag}_host_io_rate.log
   python tools/match_rate.py > $o/r03_${tag}_match_rate.log 2>&1; tail -1 $o/r03_${tag}_match_rate.log
   python bench.py --fork-level 3 --no-cpu-baseline > $o/r03_${tag}_bench_tum_fork3.log 2>&1; tail -1 $o/r03_${tag}_bench_tum_fork3.log | cut -c1-200
   python bench.py --streams 3 --no-cpu-baseline > $o/r03_${tag}_bench_tum_streams3.log 2>&1; tail -1 $o/r03_${tag}_bench_tum_streams3.log | cut -c1-200
