@@ -488,13 +488,17 @@ def main():
                         "per_rank_ms_per_step": per_rank_ms, "gather_ms_per_step": gather_ms,
                         "gather_bytes_per_rank_per_step": int(B * sharding.record_bytes(cap))})
         if not stereo and prof["k_match"][0] > 0 and os.environ.get("ORBX_MATCH_KERNEL") != "valu":
-            # the one GEMM-shaped kernel of the path: brute-force Hamming as v_mfma_i32_32x32x32_i8 (dist = |q| + |t| - 2 q.t);
-            # 2 operations per (query bit, train bit) pair against the dense int8 peak (2 x the 2.5 PFLOP/s bf16 peak).
+            # the one GEMM-shaped kernel of the path: brute-force Hamming on the matrix pipe (dist = |q| + |t| - 2 q.t), by default
+            # with FP4 operands (v_mfma_scale_f32_32x32x64_f8f6f4, dense peak 10 Pop/s), with ORBX_MATCH_KERNEL=i8 as
+            # v_mfma_i32_32x32x32_i8 (5 Pop/s); 2 operations per (query bit, train bit) pair.
             # Duration: HIP events of the calibration pass (every kernel alone on its stream).
             m_us = prof["k_match"][0] / 2 * 1e3          # per step: one launch (plus the merge kernel for small batches)
             m_ops = 2.0 * B * n_kp * n_kp * 256
-            out["roofline_mfma"] = {"bound": "mfma", "kernel": "k_match", "achieved": round(m_ops / (m_us * 1e-6) / 1e12, 1),
-                                    "peak": 5000.0, "unit": "TOP/s", "frac": round(m_ops / (m_us * 1e-6) / 1e12 / 5000.0, 4),
+            m_i8 = os.environ.get("ORBX_MATCH_KERNEL") == "i8"
+            m_peak = 5000.0 if m_i8 else 10000.0
+            out["roofline_mfma"] = {"bound": "mfma", "kernel": "k_match", "operands": "int8" if m_i8 else "fp4 (e2m1)",
+                                    "achieved": round(m_ops / (m_us * 1e-6) / 1e12, 1),
+                                    "peak": m_peak, "unit": "TOP/s", "frac": round(m_ops / (m_us * 1e-6) / 1e12 / m_peak, 4),
                                     "avg_launch_us": round(m_us, 2)}
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only (the other ranks would idle through it)
             cfps, nsample, pinned, cflags = cpu_baseline(frames, right, NF, stereo, mb, mbf)

@@ -50,7 +50,7 @@ struct orbx_handle {
     OrbxCell *d_cells = nullptr;
     OrbxFastGroup *d_groups = nullptr;
     bool resize_legacy = false;   // ORBX_RESIZE_IMPL=legacy: k_pyr_resize for every level (A/B runs)
-    bool match_valu = false;      // ORBX_MATCH_KERNEL=valu, read ONCE when the handle is created: the vector-pipe matcher (A/B runs, parity tests)
+    int match_kernel = 0;         // ORBX_MATCH_KERNEL, read ONCE when the handle is created: 0 = matrix pipe with FP4 operands (default), 1 = "valu" (vector pipe), 2 = "i8" (matrix pipe, int8 operands) -- A/B runs, parity tests
     int fast_stop = 0;      // ORBX_FAST_STOP: only read in -DORBX_TIMING_KNOBS builds
     int fast_lcap = 640;    // LDS work-list entries of k_fast_rows (ORBX_FAST_LCAP; tests shrink it to force the flush paths)
     OrbxTap *d_taps = nullptr;
@@ -334,7 +334,7 @@ extern "C" orbx_status orbx_create(const orbx_params *params, orbx_handle **out)
     orbx_handle *h = new orbx_handle();
     h->p = *params;
     if (h->p.max_batch < 1) h->p.max_batch = 1;
-    if (const char *e = getenv("ORBX_MATCH_KERNEL")) h->match_valu = strcmp(e, "valu") == 0;
+    if (const char *e = getenv("ORBX_MATCH_KERNEL")) h->match_kernel = strcmp(e, "valu") == 0 ? 1 : strcmp(e, "i8") == 0 ? 2 : 0;
     orbx_build_tables(h->p, h->tab);
     if (params->device == -2) {  // host-only handle: tables and getters, no device work
         h->host_only = true;
@@ -1089,7 +1089,7 @@ extern "C" orbx_status orbx_match_bruteforce_device(orbx_handle *h, int npairs, 
     }
     { ProfScope ps(h, ORBX_K_MATCH);
       orbx_launch_match(h->stream, npairs, out_stride, d_q, d_nq, q_stride, d_t, d_nt, t_stride, d_best_idx, d_best_dist,
-                        d_second_dist, out_stride, h->d_match_ws, h->match_valu); }
+                        d_second_dist, out_stride, h->d_match_ws, h->match_kernel); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ORBX_HIP_ERROR, hipGetErrorString(e));
     return ORBX_OK;

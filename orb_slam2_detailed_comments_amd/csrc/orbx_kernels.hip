@@ -1838,6 +1838,157 @@ __global__ __launch_bounds__(64 * MT_WAVES, QT == 2 ? 3 : 2) void k_match(const 
     }
 }
 
+// k_match on the FP4 rate of the matrix pipe (round 3).  The same bookkeeping, the same keys, the same result bits -- the
+// products come from v_mfma_scale_f32_32x32x64_f8f6f4 with both operands in e2m1: a descriptor bit is the nibble 0b0100 (2.0)
+// on the train side and 0b1110 (-4.0) on the query side, the block scale of the train operand is 2^10, so a common bit adds
+// -8 * 2^10 = -2 << 12 to the accumulator, which is LOADED with the float of key(t) = (popc(t) + 256) << 12 | index.  Every
+// partial sum is an integer below 2^24: exact in f32 (tools/mfma_fp4_probe.hip checks the instruction with such data, layout and
+// scale bytes included).  K = 64 descriptor bits per instruction at the cycles of the 32-bit-K int8 form: four MFMAs per
+// 32 x 32 distances instead of eight, and the expansion of a train tile is 28 instead of 60 vector instructions (bit 4j+k of a
+// dword -> nibble j of register k: shift + and).  Positive floats order like their bit patterns, so best / second stay
+// v_min_i32 / v_med3_i32 on the raw bits.
+typedef int mt_v8i __attribute__((ext_vector_type(8)));
+typedef float mt_v16f __attribute__((ext_vector_type(16)));
+#define MT_F4_NONE 0x7f7fffff   // FLT_MAX: "no key yet" / rows past the end (a zero descriptor adds nothing to it)
+#ifndef MT_F4_LB2
+#define MT_F4_LB2 3
+#endif
+#ifndef MT_F4_LB4
+#define MT_F4_LB4 2
+#endif
+#ifndef MT_F4_USE4
+#define MT_F4_USE4 1
+#endif
+template <int QT>
+__global__ __launch_bounds__(64 * MT_WAVES, QT == 2 ? MT_F4_LB2 : MT_F4_LB4) void k_match_f4(const uint8_t *__restrict__ q, const int *__restrict__ nq,
+                                                         long long q_stride, const uint8_t *__restrict__ t,
+                                                         const int *__restrict__ nt, long long t_stride,
+                                                         uint2 *__restrict__ partial, int *__restrict__ best_idx,
+                                                         int *__restrict__ best_dist, int *__restrict__ second_dist,
+                                                         int out_stride, int nsplit) {
+    __shared__ __attribute__((aligned(16))) float s_tk[MT_CHUNK];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pr = blockIdx.z, sp = blockIdx.y;
+    const int NQ = min(nq[pr], out_stride), NT = min(nt[pr], 1 << 20);
+    if ((int)blockIdx.x * MT_QPB(QT) >= NQ) return;
+    const int r = lane & 31, h = lane >> 5;
+    const uint8_t *qp = q + (long long)pr * q_stride;
+    const uint8_t *tp = t + (long long)pr * t_stride;
+    const int per = ((NT + 31) / 32 + nsplit - 1) / nsplit * 32;
+    const int j0 = min(NT, sp * per), j1 = min(NT, j0 + per);
+    // ---- queries: lane (r, h) holds bytes 16h .. 16h+15 of query r of each tile; dword p of them is the K block of MFMA p
+    const int qw = blockIdx.x * MT_QPB(QT) + w * MT_QPW(QT);
+    const bool wave_on = qw < NQ;
+    mt_v4i bq[QT][4];
+    int pq[QT];
+#pragma unroll
+    for (int c = 0; c < QT; ++c) {
+        const int qi = qw + 32 * c + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (qi < NQ) v = *(const uint4 *)(qp + (long long)qi * 32 + 16 * h);
+        pq[c] = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        pq[c] += __shfl_xor(pq[c], 32);
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = (vv[p] >> k) & 0x11111111u;
+                bq[c][p][k] = (int)((e << 1) | (e << 2) | (e << 3));   // 0b1110 per set bit
+            }
+        }
+    }
+    uint32_t gbest[QT], gsecond[QT];
+#pragma unroll
+    for (int c = 0; c < QT; ++c) gbest[c] = gsecond[c] = 0xffffffffu;
+    for (int c0 = j0; c0 < j1; c0 += MT_CHUNK) {
+        const int c1 = min(j1, c0 + MT_CHUNK), n = c1 - c0, npad = (n + 31) & ~31;
+        __syncthreads();
+        for (int i = threadIdx.x; i < npad; i += 64 * MT_WAVES) {
+            float key = __int_as_float(MT_F4_NONE);
+            if (i < n) {
+                const uint4 a = *(const uint4 *)(tp + (long long)(c0 + i) * 32), b = *(const uint4 *)(tp + (long long)(c0 + i) * 32 + 16);
+                const int pt = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+                key = (float)(((pt + 256) << 12) | i);   // < 2^24: exact
+            }
+            s_tk[i] = key;
+        }
+        __syncthreads();
+        if (!wave_on) continue;
+        int best[QT], second[QT];
+#pragma unroll
+        for (int c = 0; c < QT; ++c) best[c] = second[c] = MT_F4_NONE;
+        const uint8_t *trow = tp + (long long)(c0 + r) * 32 + 16 * h;
+        uint4 ta = make_uint4(0, 0, 0, 0);
+        if (r < n) ta = *(const uint4 *)trow;
+        for (int jt = 0; jt < npad; jt += 32) {
+            const uint4 tc = ta;
+            ta = make_uint4(0, 0, 0, 0);
+            if (jt + 32 + r < n) ta = *(const uint4 *)(trow + (long long)(jt + 32) * 32);
+            mt_v16f acc[QT];
+            {
+                const float4 *kp = (const float4 *)(s_tk + jt + 4 * h);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 k4 = kp[2 * g];
+                    acc[0][4 * g] = k4.x; acc[0][4 * g + 1] = k4.y; acc[0][4 * g + 2] = k4.z; acc[0][4 * g + 3] = k4.w;
+                }
+#pragma unroll
+                for (int c = 1; c < QT; ++c) acc[c] = acc[0];
+            }
+            const uint32_t tw[4] = {tc.x, tc.y, tc.z, tc.w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                mt_v8i a = {0, 0, 0, 0, 0, 0, 0, 0};
+                a[0] = (int)((tw[p] << 2) & 0x44444444u); a[1] = (int)((tw[p] << 1) & 0x44444444u);
+                a[2] = (int)(tw[p] & 0x44444444u);        a[3] = (int)((tw[p] >> 1) & 0x44444444u);
+#pragma unroll
+                for (int c = 0; c < QT; ++c) {
+                    mt_v8i b = {0, 0, 0, 0, 0, 0, 0, 0};
+                    b[0] = bq[c][p][0]; b[1] = bq[c][p][1]; b[2] = bq[c][p][2]; b[3] = bq[c][p][3];
+                    acc[c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[c], 4, 4, 0, 137, 0, 127);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+#pragma unroll
+                for (int c = 0; c < QT; ++c) {
+                    const int kc = __float_as_int(acc[c][i]);
+                    second[c] = max(min(best[c], second[c]), min(max(best[c], second[c]), kc));
+                    best[c] = min(best[c], kc);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < QT; ++c) {
+            const int bk = (int)__int_as_float(best[c]), sk = (int)__int_as_float(second[c]);   // the integer keys (exact; unused when NONE)
+            const uint32_t b = best[c] == MT_F4_NONE ? 0xffffffffu
+                                                     : ((uint32_t)((bk >> 12) + pq[c] - 256) << 20) | (uint32_t)(c0 + (bk & 4095));
+            const uint32_t s2 = second[c] == MT_F4_NONE ? 0xffffffffu
+                                                        : ((uint32_t)((sk >> 12) + pq[c] - 256) << 20) | (uint32_t)(c0 + (sk & 4095));
+            gsecond[c] = mt_min2(mt_min2(gsecond[c], s2), mt_max2(gbest[c], b));
+            gbest[c] = mt_min2(gbest[c], b);
+        }
+    }
+    if (!wave_on) return;
+#pragma unroll
+    for (int c = 0; c < QT; ++c) {
+        const uint32_t ob = (uint32_t)__shfl_xor((int)gbest[c], 32), os = (uint32_t)__shfl_xor((int)gsecond[c], 32);
+        const uint32_t second = mt_min2(mt_min2(gsecond[c], os), mt_max2(gbest[c], ob));
+        const uint32_t best = mt_min2(gbest[c], ob);
+        const int qi = qw + 32 * c + r;
+        if (h == 0 && qi < NQ) {
+            if (nsplit > 1) {
+                partial[((long long)pr * nsplit + sp) * out_stride + qi] = make_uint2(best, second);
+            } else {
+                const long long o = (long long)pr * out_stride + qi;
+                best_idx[o] = best == 0xffffffffu ? -1 : (int)(best & 0xfffffu);
+                best_dist[o] = best == 0xffffffffu ? 0x7fffffff : (int)(best >> 20);
+                second_dist[o] = second == 0xffffffffu ? 0x7fffffff : (int)(second >> 20);
+            }
+        }
+    }
+}
+
 // The same bookkeeping on the vector pipe (the round-1 kernel, ORBX_MATCH_KERNEL=valu): two queries per lane (16 dwords in
 // VGPRs); the train descriptor of an iteration is the same for the whole wave, so it is fetched with SCALAR loads
 // (s_load_dwordx8 through the scalar cache) and used as the SGPR operand of v_xor: no LDS staging, no barrier.  19 vector
@@ -2679,7 +2830,9 @@ void orbx_launch_block_dist(hipStream_t s, const uint8_t *d1, const uint8_t *d2,
 size_t orbx_match_workspace_bytes(int npairs, int out_stride) { return (size_t)npairs * MT_SPLIT * out_stride * sizeof(uint2); }
 void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,
                        const uint8_t *t, const int *nt, long long t_stride, int *best_idx, int *best_dist,
-                       int *second_dist, int out_stride, void *workspace, bool use_valu) {
+                       int *second_dist, int out_stride, void *workspace, int kernel) {
+    // kernel: 0 = matrix pipe, FP4 operands (default); 1 = vector pipe (ORBX_MATCH_KERNEL=valu); 2 = matrix pipe, int8 operands (=i8)
+    const bool use_valu = kernel == 1, f4 = kernel == 0;
     if (npairs <= 0 || max_nq <= 0) return;
     if (use_valu) {   // the vector-pipe kernel (orbx_params-free A/B switch ORBX_MATCH_KERNEL=valu, read once per handle)
         const int qblocks = (max_nq + 127) / 128;
@@ -2694,15 +2847,15 @@ void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, 
     // 512 queries per block (QT = 4, two waves per SIMD: the chip holds 2048 such waves) when the launch fills the chip that
     // way without splitting the train set; otherwise 256 per block and the train split that reaches ~4096 waves
     const long long waves4 = (long long)((max_nq + MT_QPW(4) - 1) / MT_QPW(4)) * npairs;
-    if (waves4 >= 2048) {
-        hipLaunchKernelGGL(k_match<4>, dim3((max_nq + MT_QPB(4) - 1) / MT_QPB(4), 1, npairs), dim3(64 * MT_WAVES), 0, s, q, nq,
+    if (waves4 >= 2048 && (!f4 || MT_F4_USE4)) {
+        hipLaunchKernelGGL(f4 ? k_match_f4<4> : k_match<4>, dim3((max_nq + MT_QPB(4) - 1) / MT_QPB(4), 1, npairs), dim3(64 * MT_WAVES), 0, s, q, nq,
                            q_stride, t, nt, t_stride, (uint2 *)workspace, best_idx, best_dist, second_dist, out_stride, 1);
         return;
     }
     const int qblocks = (max_nq + MT_QPB(2) - 1) / MT_QPB(2);
     const long long base = (long long)((max_nq + MT_QPW(2) - 1) / MT_QPW(2)) * npairs;
     const int nsplit = (int)std::min<long long>(MT_SPLIT, std::max<long long>(1, 4096 / base));
-    hipLaunchKernelGGL(k_match<2>, dim3(qblocks, nsplit, npairs), dim3(64 * MT_WAVES), 0, s, q, nq,
+    hipLaunchKernelGGL(f4 ? k_match_f4<2> : k_match<2>, dim3(qblocks, nsplit, npairs), dim3(64 * MT_WAVES), 0, s, q, nq,
                        q_stride, t, nt, t_stride, (uint2 *)workspace, best_idx, best_dist, second_dist, out_stride, nsplit);
     if (nsplit > 1)
         hipLaunchKernelGGL(k_match_merge, dim3((max_nq + 255) / 256, npairs), dim3(256), 0, s, nq, (const uint2 *)workspace,

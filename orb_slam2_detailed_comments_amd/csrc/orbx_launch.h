@@ -30,7 +30,7 @@ void orbx_launch_describe(hipStream_t s, const DGeom &g, int B, const uint8_t *p
                           int *counts, int *status, int cap);
 void orbx_launch_match(hipStream_t s, int npairs, int max_nq, const uint8_t *q, const int *nq, long long q_stride,
                        const uint8_t *t, const int *nt, long long t_stride, int *best_idx, int *best_dist,
-                       int *second_dist, int out_stride, void *workspace, bool use_valu);
+                       int *second_dist, int out_stride, void *workspace, int kernel);
 size_t orbx_match_workspace_bytes(int npairs, int out_stride);
 void orbx_launch_grid_build(hipStream_t s, const DGrid &gp, int nframes, const orbx_keypoint *kps, const int *counts, int fixed_n,
                             int cap, int *cell_begin, uint16_t *items);

@@ -270,12 +270,14 @@ def test_bench_size_batch_is_frame_independent():
 
 
 # ---------------------------------------------------------------------------------------- matching
-@pytest.fixture(params=["mfma", "valu"])
+@pytest.fixture(params=["mfma_fp4", "mfma_i8", "valu"])
 def match_kernel(request, monkeypatch):
-    """both Hamming kernels of the library: the matrix-core one (default) and the xor + popcount one (ORBX_MATCH_KERNEL=valu,
-    read by the launcher at every launch)"""
+    """the three Hamming kernels of the library: the matrix-pipe one with FP4 operands (default), the matrix-pipe one with int8
+    operands (ORBX_MATCH_KERNEL=i8) and the xor + popcount one (ORBX_MATCH_KERNEL=valu); the variable is read once per handle"""
     if request.param == "valu":
         monkeypatch.setenv("ORBX_MATCH_KERNEL", "valu")
+    elif request.param == "mfma_i8":
+        monkeypatch.setenv("ORBX_MATCH_KERNEL", "i8")
     else:
         monkeypatch.delenv("ORBX_MATCH_KERNEL", raising=False)
     return request.param

@@ -4,6 +4,7 @@ t=${1:?tag}
 o=gpurun_out
 python bench.py --stages > $o/r03_${t}_final_bench_tum.log 2>&1; tail -1 $o/r03_${t}_final_bench_tum.log | cut -c1-1400
 ORBX_MATCH_KERNEL=valu python bench.py --no-cpu-baseline > $o/r03_${t}_final_bench_tum_match_valu.log 2>&1; tail -1 $o/r03_${t}_final_bench_tum_match_valu.log | cut -c1-140
+ORBX_MATCH_KERNEL=i8 python bench.py --no-cpu-baseline > $o/r03_${t}_final_bench_tum_match_i8.log 2>&1; tail -1 $o/r03_${t}_final_bench_tum_match_i8.log | cut -c1-140
 for c in kitti_stereo euroc_stereo hd1080; do
   python bench.py --config $c --stages > $o/r03_${t}_final_bench_$c.log 2>&1
   tail -1 $o/r03_${t}_final_bench_$c.log | python3 -c "
