@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from orb_slam2_detailed_comments_amd import build
 
 SLOTS = {"k_pyr_l0": ["k_pyr_l0"], "k_pyr_resize": ["k_pyr_resize_rows", "k_pyr_resize"], "k_fast_rows": ["k_fast_rows"],
-         "k_quadtree": ["k_quadtree"], "k_describe": ["k_describe"], "k_match": ["k_match", "k_match_merge", "k_stereo_rows", "k_stereo_batch", "k_stereo_cut"]}
+         "k_quadtree": ["k_quadtree"], "k_describe": ["k_describe"], "k_match": ["k_match", "k_match_f4", "k_match_merge", "k_stereo_rows", "k_stereo_batch", "k_stereo_cut"]}
 
 
 def main():

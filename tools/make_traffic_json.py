@@ -16,7 +16,7 @@ SLOTS = {
     "k_fast_rows": ["k_fast_rows"],
     "k_quadtree": ["k_quadtree"],
     "k_describe": ["k_describe"],
-    "k_match": ["k_match", "k_match_merge", "k_stereo_rows", "k_stereo_batch", "k_stereo_cut"],   # (stereo configs: the stereo match)
+    "k_match": ["k_match", "k_match_f4", "k_match_merge", "k_stereo_rows", "k_stereo_batch", "k_stereo_cut"],   # (stereo configs: the stereo match)
 }
 
 
