@@ -450,7 +450,10 @@ __device__ __forceinline__ void orbx_wave_sync() {
 // tile requested before the NMS of the current one: the staging instructions are ~5 % of the kernel's issue slots and the
 // register prefetch hides the load latency better than a wait on vmcnt does.  Not kept; git history has it.)
 #ifndef FR_WPS
-#define FR_WPS 4
+#define FR_WPS 5
+#endif
+#ifndef FR_CCAP
+#define FR_CCAP 256     // corner-list entries per group (see orbx_launch_fast_rows)
 #endif
 #ifndef FR_GPW
 #define FR_GPW 2        // groups per wave
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
                                                           const OrbxFastGroup *__restrict__ groups,
                                                           const uint8_t *__restrict__ pyr, uint2 *__restrict__ cand,
                                                           int *__restrict__ cand_cursor, int *__restrict__ status, int rows,
-                                                          int lcap, int ngroups, int gpw, int dbg_stop) {
+                                                          int lcap, int ngroups, int gpw, int dbg_stop, int ccap) {
     // dbg_stop (ORBX_FAST_STOP, phase-timing builds only, -DORBX_TIMING_KNOBS; results are wrong unless 0): 1 = after
     // staging, 2 = after the pre-test, 3 = after the ring test, 4 = before NMS.  The shipped library pins it to 0.
 #ifndef ORBX_TIMING_KNOBS
@@ -606,8 +609,11 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
 #endif
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
     uint32_t *s_tile = (uint32_t *)fast_smem;
-    uint8_t *s_score = fast_smem + rows * FR_TP;
-    uint16_t *s_list = (uint16_t *)(s_score + rows * FR_TP);   // lcap entries + one private dummy dword per lane
+    // tile | score map (16-byte aligned: cleared with 16-byte stores) | work list (lcap entries + one private dummy dword per
+    // lane) | corner list of the group (ccap entries: a group with more corners takes the dense NMS rescan)
+    const int map_bytes = (rows * FR_TP + 15) & ~15;
+    uint8_t *s_score = fast_smem + map_bytes;
+    uint16_t *s_list = (uint16_t *)(s_score + map_bytes);
     uint16_t *s_corn = s_list + lcap + 128;
     const int lane = threadIdx.x;
     const int f = blockIdx.x;   // frame fastest: all groups of one frame share one XCD's L2
@@ -784,7 +790,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
             if (dbg_stop == 2) { if (n == 12345) cand_cursor[0] = n; continue; }
             const int ncorn = fr_ring_and_score(cx, n, th, dbg_stop);
             // keep the corners for the NMS walk while they fit
-            if (!overflow && nctot + ncorn <= lcap) {
+            if (!overflow && nctot + ncorn <= ccap) {
                 for (int e = lane; e < ncorn; e += 64) s_corn[nctot + e] = s_list[e];
                 nctot += ncorn;
             } else {
@@ -2724,13 +2730,19 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
                            int dbg_stop) {
     if (ngroups <= 0) return;
     lcap = (max(lcap, 64) + 1) & ~1;
-    max_ch = (max_ch + 3) & ~3;   // tile and score map sizes multiples of 16 bytes
-    const size_t smem = (size_t)2 * max_ch * FR_TP + (size_t)4 * lcap + 256;
+    // LDS per wave decides how many waves a CU holds (the kernel loses 7 % per wave it cannot place): the corner list of a group is
+    // sized for its usual load, FR_CCAP entries (the average group has ~130 corners), not for the work list's worst case -- a
+    // group with more corners than that runs its NMS as the dense rescan of the score map -- and tile / score map are rounded to
+    // 16 bytes, not to four rows: 7 680 bytes at 640x480 (six 1 280-byte granules: 21 waves per CU by LDS, 20 by registers)
+    // instead of 8 896 (seven granules: 18).
+    const int ccap = min(lcap, FR_CCAP);
+    const size_t map_bytes = ((size_t)max_ch * FR_TP + 15) & ~(size_t)15;
+    const size_t smem = 2 * map_bytes + (size_t)2 * lcap + 256 + (size_t)2 * ccap;
     // groups per wave: FR_GPW when the launch has waves to spare (the second group's tile is prefetched while the first
     // is processed); one per wave for small batches, where the serial length of a wave is what the caller waits for
     const int gpw = (long long)B * ngroups >= 16384 ? FR_GPW : 1;
     hipLaunchKernelGGL(k_fast_rows, dim3(B, (ngroups + gpw - 1) / gpw), dim3(64), smem, s, g, cells, groups, pyr, cand,
-                       cand_cursor, status, max_ch, lcap, ngroups, gpw, dbg_stop);
+                       cand_cursor, status, max_ch, lcap, ngroups, gpw, dbg_stop, ccap);
 }
 void orbx_launch_undistort(hipStream_t s, int B, int max_n, int cap, const double *K4, const double *k14, int identity,
                            const orbx_keypoint *kps, const int *counts, orbx_keypoint *out) {

@@ -2,7 +2,7 @@
 # A/B of FAST kernel variants on one box: tools/ab_fast.sh "label:ENV=.. ENV=.." ...   (each run prints fps + per-kernel ms)
 for spec in "$@"; do
   label=${spec%%:*}; envs=${spec#*:}
-  env $envs timeout -k 10 200 python bench.py --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | python -c "
+  env $envs timeout -k 10 200 python bench.py --no-cpu-baseline --steps ${AB_STEPS:-10} --warmup 3 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
