@@ -753,6 +753,7 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
                 const unsigned long long m = orbx_ballot(cnd);                                                          \
                 *(fr_lds_u16 *)(uintptr_t)(cnd ? nb + 2u * (uint32_t)orbx_wave_rank(m) : dummy) = (uint16_t)code;       \
                 nb += 2u * (uint32_t)__popcll(m);                                                                       \
+                asm("" : "+s"(nb));   /* ONE scalar cursor: a lane's slot stays mbcnt, mbcnt, v_lshl_add (no split into count + base) */ \
                 code += 0x100u;                                                                                         \
             }
             // full chunks of 7 rows while the list is guaranteed to take them
