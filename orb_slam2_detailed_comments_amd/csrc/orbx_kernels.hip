@@ -480,16 +480,19 @@ struct FrCtx {
 // full 16-ring test of list[0..n) at threshold th, corners compacted IN PLACE to the front of the list, their scores
 // written to the score map; returns the number of corners
 __device__ __forceinline__ int fr_ring_and_score(const FrCtx &c, int n, int th, int dbg_stop) {
-    const int ro[16] = {3 * FR_TP,      3 * FR_TP + 1,  2 * FR_TP + 2,  FR_TP + 3, 3,  -FR_TP + 3,
-                        -2 * FR_TP + 2, -3 * FR_TP + 1, -3 * FR_TP,     -3 * FR_TP - 1, -2 * FR_TP - 2,
-                        -FR_TP - 3,     -3,             FR_TP - 3,      2 * FR_TP - 2,  3 * FR_TP - 1};
+    // offsets from the TOP-LEFT corner of the pixel's 7x7 window: none is negative, so every ring read is base + immediate (a DS
+    // offset is unsigned: the seven negative offsets of a centre-based table cost a v_add each, per round)
+    const int rc = 3 * FR_TP + 3;
+    const int ro[16] = {rc + 3 * FR_TP,      rc + 3 * FR_TP + 1,  rc + 2 * FR_TP + 2,  rc + FR_TP + 3, rc + 3,  rc - FR_TP + 3,
+                        rc - 2 * FR_TP + 2, rc - 3 * FR_TP + 1, rc - 3 * FR_TP,     rc - 3 * FR_TP - 1, rc - 2 * FR_TP - 2,
+                        rc - FR_TP - 3,     rc - 3,             rc + FR_TP - 3,      rc + 2 * FR_TP - 2,  rc + 3 * FR_TP - 1};
     int ncorn = 0;
     for (int e0 = 0; e0 < n; e0 += 64) {
         const int e = e0 + c.lane;
         const bool valid = e < n;
         const uint16_t code = valid ? c.list[e] : (uint16_t)(3 << 8);
-        const uint8_t *ptr = c.tile + (code >> 8) * FR_TP + 3 + (code & 0xff);
-        const int v = ptr[0];
+        const uint8_t *ptr = c.tile + ((code >> 8) - 3) * FR_TP + (code & 0xff);   // window corner: row - 3, column - 3 (rows start at 3)
+        const int v = ptr[rc];
         const int hi = v + th, lo = v - th;
         // ring masks by shift-in: mask = 2*mask + (compare) is one v_cmp + one v_addc per ring pixel and polarity
         // (ring position k lands on bit 15-k; a circular run of 9 is a run of 9 in either direction)
@@ -522,10 +525,10 @@ __device__ __forceinline__ int fr_ring_and_score(const FrCtx &c, int n, int th, 
     for (int e = c.lane; e < ncorn; e += 64) {
         const uint16_t code = c.list[e];
         const int off = ((code >> 8) & 0x7f) * FR_TP + 3 + (code & 0xff);
-        const uint8_t *ptr = c.tile + off;
+        const uint8_t *ptr = c.tile + off - rc;
         // darker ring: complement both sides (255 - x) - (255 - v) = v - x, so one instruction stream serves both cases
         const fr_u16 flip = (code & 0x8000u) != 0 ? (fr_u16)0 : (fr_u16)0xff;
-        const fr_i16 v = (fr_i16)((fr_u16)ptr[0] ^ flip);
+        const fr_i16 v = (fr_i16)((fr_u16)ptr[rc] ^ flip);
         fr_i16 d[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) d[k] = (fr_i16)((fr_i16)((fr_u16)ptr[ro[k]] ^ flip) - v);
@@ -561,11 +564,11 @@ __device__ __forceinline__ void fr_nms(const FrCtx &c, const FrCells &gc, const 
         const uint16_t code = valid ? list[e] : (uint16_t)(3 << 8);
         const int col = code & 0xff, ly = (code >> 8) & 0x7f;
         const bool second = col >= gc.iw0;
-        const uint8_t *sp = c.score + ly * FR_TP + 3 + col;
-        const int sc = sp[0];
-        int l0 = sp[-FR_TP - 1], l1 = sp[-1], l2 = sp[FR_TP - 1];
-        int r0 = sp[-FR_TP + 1], r1 = sp[1], r2 = sp[FR_TP + 1];
-        const int u = sp[-FR_TP], dn = sp[FR_TP];
+        const uint8_t *sp = c.score + (ly - 1) * FR_TP + 2 + col;   // top-left of the 3x3 neighbourhood: immediates only
+        const int sc = sp[FR_TP + 1];
+        int l0 = sp[0], l1 = sp[FR_TP], l2 = sp[2 * FR_TP];
+        int r0 = sp[2], r1 = sp[FR_TP + 2], r2 = sp[2 * FR_TP + 2];
+        const int u = sp[1], dn = sp[2 * FR_TP + 1];
         // the score map is shared by the two cells: the neighbours across the seam belong to the other cell's cv::FAST call
         const bool seam_l = col == gc.iw0, seam_r = col == gc.iw0 - 1;
         l0 = seam_l ? 0 : l0; l1 = seam_l ? 0 : l1; l2 = seam_l ? 0 : l2;
