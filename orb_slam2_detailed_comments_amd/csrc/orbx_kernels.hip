@@ -477,6 +477,105 @@ struct FrCtx {
     int lane;
 };
 
+#ifndef FR_UNIFIED
+#define FR_UNIFIED 1
+#endif
+#if FR_UNIFIED
+// Corner test and score of list[0..n) at threshold th in ONE pass per candidate; corners compacted IN PLACE to the front of the
+// list, their scores written to the score map; returns the number of corners.
+//   cv::FAST's test (9 contiguous ring pixels all brighter than v + th, or all darker than v - th) is "the largest over the 16
+// arcs of the smallest signed difference on the arc exceeds th" -- which is cv::cornerScore's own quantity (score + 1).  So the
+// min/max network of the score IS the test: 16-bit min / max issue at the full rate, where the ring masks of the separate test
+// (v_cmp + v_addc per ring pixel and polarity, fr_ring_and_score below) are all half-rate, and the second pass over the corners
+// (17 LDS reads per corner again) disappears.
+//   One polarity per candidate: d = ring - v, and the compass pixels (ring 0 / 4 / 8 / 12: the walk's pre-test) say which margin
+// is the larger one, s1 = min(max(d0, d8), max(d4, d12)) (brighter) or -s2 = -max(min(d0, d8), min(d4, d12)) (darker).  Darker
+// candidates run the same network on ~d = (v - ring) - 1 with the start value th - 1 (one xor per ring pixel, no negation):
+// corner <=> result > start, score = result - 1 - f with f = 0 / -1.  A candidate that passes BOTH pre-tests (a pixel half way
+// up a strong edge: < 1 % of the candidates) and fails its larger polarity may still be a corner of the other one: it is pushed on
+// a small stack (the 64 dummy dwords the walk's masked lanes write to, free during these rounds) and re-run with the polarity
+// forced the other way in a later round; the stack is drained whenever it could not take another round's worth.
+// one round of up to 64 candidates.  FULL: 64 entries of the main list, every lane busy, nothing selected per lane.  Otherwise lanes
+// [0, cm) take main entries and lanes [cm, cm + cs) entries popped from the stack, which run with the polarity forced the other way.
+template <bool FULL>
+__device__ __forceinline__ void fr_round(const FrCtx &c, const uint16_t *src_main, int cm, const uint16_t *src_stack, int cs,
+                                         int th, uint16_t *stack, int &ncorn, int &nredo) {
+    const int rc = 3 * FR_TP + 3;
+    const int ro[16] = {rc + 3 * FR_TP,      rc + 3 * FR_TP + 1,  rc + 2 * FR_TP + 2,  rc + FR_TP + 3, rc + 3,  rc - FR_TP + 3,
+                        rc - 2 * FR_TP + 2, rc - 3 * FR_TP + 1, rc - 3 * FR_TP,     rc - 3 * FR_TP - 1, rc - 2 * FR_TP - 2,
+                        rc - FR_TP - 3,     rc - 3,             rc + FR_TP - 3,      rc + 2 * FR_TP - 2,  rc + 3 * FR_TP - 1};
+    const bool is_main = FULL || c.lane < cm;
+    uint16_t code;
+    fr_i16 thl;
+    if (FULL) {
+        code = src_main[c.lane];
+        thl = (fr_i16)th;
+    } else {
+        const bool valid = c.lane < cm + cs;
+        const uint16_t *src = is_main ? src_main + c.lane : src_stack + (c.lane - cm);
+        code = valid ? *src : (uint16_t)(3 << 8);
+        // lanes without an entry carry a threshold no 8-bit difference reaches: no lane mask in the tests below
+        thl = valid ? (fr_i16)th : (fr_i16)0x4000;
+    }
+    const int off = ((code >> 8) - 3) * FR_TP + (code & 0xff);   // window corner: row - 3, column - 3 (rows start at 3)
+    const uint8_t *ptr = c.tile + off;
+    const fr_i16 v = (fr_i16)ptr[rc];
+    fr_i16 d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = (fr_i16)((fr_i16)ptr[ro[k]] - v);
+    const fr_i16 s1 = fr_smin(fr_smax(d[0], d[8]), fr_smax(d[4], d[12]));
+    const fr_i16 s2 = fr_smax(fr_smin(d[0], d[8]), fr_smin(d[4], d[12]));
+    // both pre-tests pass (th < 256: no 16-bit overflow anywhere here)
+    const bool both = fr_smin(s1, (fr_i16)(-s2)) > thl;
+    // -1: the darker margin is the larger one; an entry from the stack takes the other polarity
+    uint32_t f32 = (uint32_t)(int)(fr_i16)((fr_i16)(s1 + s2) >> 15);
+    if (!FULL) f32 ^= is_main ? 0u : 0xffffffffu;
+    asm("" : "+v"(f32));   // ONE register: the 16 flips below stay plain v_xor (the compiler otherwise folds the terms into 16 three-input ops)
+    const fr_i16 f = (fr_i16)f32;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = (fr_i16)(d[k] ^ f);
+    const fr_i16 start = (fr_i16)(thl + f);
+    fr_i16 a0 = start;
+    fr_i16 m2[16], m4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m2[k] = fr_smin(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m4[k] = fr_smin(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a0 = fr_smax(a0, fr_smin(fr_smin(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
+    const bool corner = a0 > start;
+    const unsigned long long m = orbx_ballot(corner);
+    if (corner) {
+        c.list[ncorn + orbx_wave_rank(m)] = code;   // index < the entries already read: this round's are in registers
+        c.score[off + rc] = (uint8_t)(a0 - 1 - f);
+    }
+    ncorn += __popcll(m);
+    const bool redo = both && !corner && is_main;
+    const unsigned long long mr = orbx_ballot(redo);
+    if (mr != 0ull) {
+        if (redo) stack[nredo + orbx_wave_rank(mr)] = code;
+        nredo += __popcll(mr);
+    }
+}
+__device__ __forceinline__ int fr_ring_and_score(const FrCtx &c, int n, int th, int dbg_stop) {
+    uint16_t *const stack = c.list + c.lcap;   // 128 entries
+    int ncorn = 0, nredo = 0, e0 = 0;
+    // full rounds of the main list (a round pushes at most 64 entries: with at most 64 on the stack before it, 128 hold them)
+    for (; n - e0 >= 64 && nredo <= 64; e0 += 64) fr_round<true>(c, c.list + e0, 64, stack, 0, th, stack, ncorn, nredo);
+    // the rest of the main list and the stack, the stack in whatever lanes the main entries leave free
+    for (;;) {
+        const int cm = nredo > 64 ? 0 : min(n - e0, 64);
+        const int cs = min(nredo, 64 - cm);
+        if (cm + cs == 0) break;
+        nredo -= cs;
+        fr_round<false>(c, c.list + e0, cm, stack + nredo, cs, th, stack, ncorn, nredo);
+        e0 += cm;
+    }
+    orbx_wave_sync();
+    (void)dbg_stop;
+    return ncorn;
+}
+#else
 // full 16-ring test of list[0..n) at threshold th, corners compacted IN PLACE to the front of the list, their scores
 // written to the score map; returns the number of corners
 __device__ __forceinline__ int fr_ring_and_score(const FrCtx &c, int n, int th, int dbg_stop) {
@@ -545,6 +644,7 @@ __device__ __forceinline__ int fr_ring_and_score(const FrCtx &c, int n, int th, 
     orbx_wave_sync();
     return ncorn;
 }
+#endif
 
 
 // strict 3x3 NMS of list[0..n) among the corners of the SAME cell, survivors straight to the cell's slot range
@@ -743,6 +843,24 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
             // store could alias them as far as the compiler knows, so it would not hoist them itself); the row after
             // the last one is read but never used (it is the first row of the score map)
             uint32_t nx0 = pr[3 * FR_TP], nx4 = pr[3], nx12 = pr[-3];   // (32-bit carriers: no re-extension in the loop)
+            uint32_t probe_s = 0, probe_v = 0; (void)probe_s; (void)probe_v;
+#ifndef FR_WALK_IF
+#define FR_WALK_IF 1
+#endif
+// issue-cost probes (measurement builds only; the result bits do not change): FR_PROBE_S = 4 scalar, FR_PROBE_V = 4 vector
+// filler instructions per walked row (profiles/r03_fast_issue_probe.md)
+#if defined(FR_PROBE_S)
+#define FR_PROBE() asm volatile("s_xor_b32 %0, %0, 1\n\ts_xor_b32 %0, %0, 1\n\ts_xor_b32 %0, %0, 1\n\ts_xor_b32 %0, %0, 1" : "+s"(probe_s));
+#elif defined(FR_PROBE_V)
+#define FR_PROBE() asm volatile("v_xor_b32 %0, 1, %0\n\tv_xor_b32 %0, 1, %0\n\tv_xor_b32 %0, 1, %0\n\tv_xor_b32 %0, 1, %0" : "+v"(probe_v));
+#else
+#define FR_PROBE()
+#endif
+#if FR_WALK_IF
+#define FR_STORE(cnd, m, nb, dummy, code) (void)(dummy); if (cnd) *(fr_lds_u16 *)(uintptr_t)((nb) + 2u * (uint32_t)orbx_wave_rank(m)) = (uint16_t)(code);
+#else
+#define FR_STORE(cnd, m, nb, dummy, code) *(fr_lds_u16 *)(uintptr_t)((cnd) ? (nb) + 2u * (uint32_t)orbx_wave_rank(m) : (dummy)) = (uint16_t)(code);
+#endif
 #define FR_STEP(R8, C, R0)                                                                                              \
             {                                                                                                           \
                 R0 = (fr_u16)nx0;                                                                                       \
@@ -754,10 +872,11 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
                 const fr_u16 Bm = fr_max(fr_min(R0, R8), fr_min(r4, r12));                                              \
                 const bool cnd = fr_smax((fr_i16)(A - C), (fr_i16)(C - Bm)) > thv;                                      \
                 const unsigned long long m = orbx_ballot(cnd);                                                          \
-                *(fr_lds_u16 *)(uintptr_t)(cnd ? nb + 2u * (uint32_t)orbx_wave_rank(m) : dummy) = (uint16_t)code;       \
+                FR_STORE(cnd, m, nb, dummy, code)                                                                       \
                 nb += 2u * (uint32_t)__popcll(m);                                                                       \
                 asm("" : "+s"(nb));   /* ONE scalar cursor: a lane's slot stays mbcnt, mbcnt, v_lshl_add (no split into count + base) */ \
                 code += 0x100u;                                                                                         \
+                FR_PROBE()                                                                                              \
             }
             // full chunks of 7 rows while the list is guaranteed to take them
             while (y + 7 <= yend && nb + 7u * 128u <= list0 + 2u * (uint32_t)lcap) {
@@ -1328,18 +1447,42 @@ typedef const __attribute__((address_space(3))) uint16_t *orbx_lds_u16p;
 typedef const __attribute__((address_space(3))) uint32_t *orbx_lds_u32p;
 // I = sum_i k_i v[r][c + i], i = 0..6, for the u16 element at LDS byte address `adr` (DS_COLFIRST): the 8 elements of the
 // dword-aligned 16-byte window around them, against the weights shifted by the parity of c
+#ifndef DS_UNALIGNED
+#define DS_UNALIGNED 0
+#endif
 __device__ __forceinline__ uint32_t orbx_ds_tap(uint32_t adr) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#if DS_UNALIGNED
+    // the window read where it starts (a 2-byte-aligned LDS address: gfx950 reads unaligned b64 / b128), constant weights:
+    // no alignment mask, no parity test, no weight selects
+    uint32_t d0, d1, d2, d3;
+#if DS_UNALIGNED == 2
+    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
+    const u32x4_u q = *(const __attribute__((address_space(3))) u32x4_u *)(uintptr_t)adr;
+    d0 = q.x; d1 = q.y; d2 = q.z; d3 = q.w;
+#else
+    typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(2)));
+    const volatile __attribute__((address_space(3))) u32x2_u *wq = (const volatile __attribute__((address_space(3))) u32x2_u *)(uintptr_t)adr;
+    const u32x2_u qa = wq[0], qb = wq[1];   // (volatile: two ds_read_b64, not one ds_read_b128 -- 73 against 2 x 8.6 issue cycles in the rate tables)
+    d0 = qa.x; d1 = qa.y; d2 = qb.x; d3 = qb.y;
+#endif
+    uint32_t J = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d0), __builtin_bit_cast(u16x2, 18u | (34u << 16)), 0u, false);
+    J = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d1), __builtin_bit_cast(u16x2, 49u | (55u << 16)), J, false);
+    J = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d2), __builtin_bit_cast(u16x2, 49u | (34u << 16)), J, false);
+    J = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d3), __builtin_bit_cast(u16x2, 18u), J, false);
+    return J;
+#else
     const bool odd = (adr & 2u) != 0;
     const orbx_lds_u32p wp = (orbx_lds_u32p)(uintptr_t)(adr & ~3u);
     const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3];
     const uint32_t w0 = odd ? (18u << 16) : (18u | (34u << 16)), w1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16)),
                    w2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), w3 = odd ? (34u | (18u << 16)) : 18u;
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     uint32_t I = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d0), __builtin_bit_cast(u16x2, w0), 0u, false);
     I = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d1), __builtin_bit_cast(u16x2, w1), I, false);
     I = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d2), __builtin_bit_cast(u16x2, w2), I, false);
     I = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d3), __builtin_bit_cast(u16x2, w3), I, false);
     return I;   // < 2^24.01
+#endif
 }
 template <int FPM>
 __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
@@ -1381,12 +1524,30 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
 #endif
     const int *lc = lvl_count + f * g.nlevels;
     int total = 0, level = 0, slot = oi;
+#ifndef DS_LEVELS8
+#define DS_LEVELS8 1
+#endif
+    if (DS_LEVELS8 && g.nlevels == 8) {
+        // every ORB-SLAM2 configuration: the eight counts in one scalar load, then compares and selects only, and ONE table
+        // load for the level found (the general loop below pays two dependent scalar loads and two branches per level:
+        // ~120 scalar instructions and eight memory round trips in front of every keypoint)
+        const int4 ca = *(const int4 *)lc, cb = *(const int4 *)(lc + 4);
+        const int cnt[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+        int base = 0;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            if (oi >= total) { level = l; base = total; }
+            total += cnt[l];
+        }
+        slot = g.lv[level].kp_begin + (oi - base);
+    } else {
 #pragma unroll
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         if (l < g.nlevels) {
             if (oi >= total) { level = l; slot = g.lv[l].kp_begin + (oi - total); }
             total += lc[l];
         }
+    }
     }
     if (oi == 0 && lane == 0) {
         counts[f] = min(total, cap);
