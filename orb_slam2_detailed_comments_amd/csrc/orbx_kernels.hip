@@ -519,6 +519,34 @@ __device__ __forceinline__ void fr_round(const FrCtx &c, const uint16_t *src_mai
     }
     const int off = ((code >> 8) - 3) * FR_TP + (code & 0xff);   // window corner: row - 3, column - 3 (rows start at 3)
     const uint8_t *ptr = c.tile + off;
+#ifndef FR_SGN
+#define FR_SGN 1
+#endif
+#if FR_SGN
+    // d = +-(ring - v) as ONE multiply-add per ring pixel (sgn * x - sgn * v), the sign from the four compass pixels first
+    const int v = ptr[rc];
+    int x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = ptr[ro[k]];
+    const fr_i16 c0 = (fr_i16)(x[0] - v), c4 = (fr_i16)(x[4] - v), c8 = (fr_i16)(x[8] - v), c12 = (fr_i16)(x[12] - v);
+    const fr_i16 s1 = fr_smin(fr_smax(c0, c8), fr_smax(c4, c12));
+    const fr_i16 s2 = fr_smax(fr_smin(c0, c8), fr_smin(c4, c12));
+    // both pre-tests pass (th < 256: no 16-bit overflow anywhere here)
+    const bool both = fr_smin(s1, (fr_i16)(-s2)) > thl;
+    // -1: the darker margin is the larger one; an entry from the stack takes the other polarity
+    int sgn = ((int)(fr_i16)(s1 + s2) >> 15) | 1;
+    if (!FULL) sgn = is_main ? sgn : -sgn;
+    const int cv = __mul24(-sgn, v);
+    fr_i16 d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int t;   // (as written in C the compiler factors the sign out again: a subtraction and a multiplication per pixel)
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t) : "v"(x[k]), "v"(sgn), "v"(cv));
+        d[k] = (fr_i16)t;
+    }
+    const fr_i16 start = thl;
+    const fr_i16 f = 0;
+#else
     const fr_i16 v = (fr_i16)ptr[rc];
     fr_i16 d[16];
 #pragma unroll
@@ -535,14 +563,31 @@ __device__ __forceinline__ void fr_round(const FrCtx &c, const uint16_t *src_mai
 #pragma unroll
     for (int k = 0; k < 16; ++k) d[k] = (fr_i16)(d[k] ^ f);
     const fr_i16 start = (fr_i16)(thl + f);
+#endif
     fr_i16 a0 = start;
     fr_i16 m2[16], m4[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) m2[k] = fr_smin(d[k], d[(k + 1) & 15]);
 #pragma unroll
     for (int k = 0; k < 16; ++k) m4[k] = fr_smin(m2[k], m2[(k + 2) & 15]);
+#ifndef FR_NOMIN3
+#define FR_NOMIN3 1
+#endif
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a0 = fr_smax(a0, fr_smin(fr_smin(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
+    for (int k = 0; k < 16; ++k) {
+#if FR_NOMIN3
+        // two-input forms only: v_min3_i16 / v_max3_i16 issue at a QUARTER of the rate of v_min_i16 on gfx950 (8.4 against 2.8
+        // cycles per wave, tools/valu_rate6.hip) -- three two-input operations cost as much as one three-input one
+        fr_i16 m8 = fr_smin(m4[k], m4[(k + 4) & 15]);
+        asm("" : "+v"(m8));
+        fr_i16 w9 = fr_smin(m8, d[(k + 8) & 15]);
+        asm("" : "+v"(w9));
+        a0 = fr_smax(a0, w9);
+        asm("" : "+v"(a0));
+#else
+        a0 = fr_smax(a0, fr_smin(fr_smin(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]));
+#endif
+    }
     const bool corner = a0 > start;
     const unsigned long long m = orbx_ballot(corner);
     if (corner) {
@@ -1447,31 +1492,8 @@ typedef const __attribute__((address_space(3))) uint16_t *orbx_lds_u16p;
 typedef const __attribute__((address_space(3))) uint32_t *orbx_lds_u32p;
 // I = sum_i k_i v[r][c + i], i = 0..6, for the u16 element at LDS byte address `adr` (DS_COLFIRST): the 8 elements of the
 // dword-aligned 16-byte window around them, against the weights shifted by the parity of c
-#ifndef DS_UNALIGNED
-#define DS_UNALIGNED 0
-#endif
 __device__ __forceinline__ uint32_t orbx_ds_tap(uint32_t adr) {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-#if DS_UNALIGNED
-    // the window read where it starts (a 2-byte-aligned LDS address: gfx950 reads unaligned b64 / b128), constant weights:
-    // no alignment mask, no parity test, no weight selects
-    uint32_t d0, d1, d2, d3;
-#if DS_UNALIGNED == 2
-    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
-    const u32x4_u q = *(const __attribute__((address_space(3))) u32x4_u *)(uintptr_t)adr;
-    d0 = q.x; d1 = q.y; d2 = q.z; d3 = q.w;
-#else
-    typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(2)));
-    const volatile __attribute__((address_space(3))) u32x2_u *wq = (const volatile __attribute__((address_space(3))) u32x2_u *)(uintptr_t)adr;
-    const u32x2_u qa = wq[0], qb = wq[1];   // (volatile: two ds_read_b64, not one ds_read_b128 -- 73 against 2 x 8.6 issue cycles in the rate tables)
-    d0 = qa.x; d1 = qa.y; d2 = qb.x; d3 = qb.y;
-#endif
-    uint32_t J = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d0), __builtin_bit_cast(u16x2, 18u | (34u << 16)), 0u, false);
-    J = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d1), __builtin_bit_cast(u16x2, 49u | (55u << 16)), J, false);
-    J = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d2), __builtin_bit_cast(u16x2, 49u | (34u << 16)), J, false);
-    J = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d3), __builtin_bit_cast(u16x2, 18u), J, false);
-    return J;
-#else
     const bool odd = (adr & 2u) != 0;
     const orbx_lds_u32p wp = (orbx_lds_u32p)(uintptr_t)(adr & ~3u);
     const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3];
@@ -1482,7 +1504,6 @@ __device__ __forceinline__ uint32_t orbx_ds_tap(uint32_t adr) {
     I = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d2), __builtin_bit_cast(u16x2, w2), I, false);
     I = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d3), __builtin_bit_cast(u16x2, w3), I, false);
     return I;   // < 2^24.01
-#endif
 }
 template <int FPM>
 __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const uint8_t *__restrict__ pyr,
