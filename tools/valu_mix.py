@@ -7,10 +7,12 @@ Issue cost per wave64 VALU instruction on one SIMD-32, from the round-1 issue-ra
   3 cycles            : shifts, v_fmac_f32;
   half rate (4 cycles): everything VOP3 / VOP3P / DPP / SDWA encoded, every v_cmp, 32-bit integer min / max, v_mul_u32_u24, v_cvt_*,
                         v_rndne, f32 min / max, and a VOP2 instruction with an SGPR source; MFMA and transcendental ops are not VALU
-                        issue in this sense and are listed apart.
+                        issue in this sense and are listed apart;
+  quarter rate (8 cycles): the THREE-input 16-bit forms v_min3 / v_max3 / v_med3 _i16 / _u16 (8.3-8.5 cycles measured, round 3,
+                        tools/valu_rate6.hip: one of them costs as much as three v_min_i16) and the full 32-bit multiplies.
 The mix is STATIC (every instruction of the kernel counted once, no execution weights): an estimate of the class share, not a count.
 
-  tools/valu_mix.py [liborbx.so]      ->  JSON {kernel: {valu, full, mid, half, cycles_per_valu}}"""
+  tools/valu_mix.py [liborbx.so]      ->  JSON {kernel: {valu, full, mid, half, quarter, cycles_per_valu}}"""
 import json, os, re, subprocess, sys, tempfile
 
 HALF_NAMES = ("v_perm_b32", "v_alignbyte", "v_alignbit", "v_bfe_", "v_bfi_", "v_lshl_add", "v_add_lshl", "v_add3", "v_mad_", "v_and_or", "v_or3",
@@ -18,6 +20,7 @@ HALF_NAMES = ("v_perm_b32", "v_alignbyte", "v_alignbit", "v_bfe_", "v_bfi_", "v_
               "v_mul_u32_u24", "v_mul_i32_i24", "v_mul_lo", "v_mul_hi", "v_cvt", "v_rndne", "v_min_f32", "v_max_f32", "v_min_i32", "v_max_i32",
               "v_min_u32", "v_max_u32", "v_cmp", "v_cndmask_b32_e64", "v_xad", "v_div", "v_ldexp", "v_frexp", "v_trunc", "v_floor", "v_fract")
 MID_NAMES = ("v_lshlrev", "v_lshrrev", "v_ashrrev", "v_fmac")
+QUARTER_NAMES = ("v_min3_i16", "v_max3_i16", "v_med3_i16", "v_min3_u16", "v_max3_u16", "v_med3_u16", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32")
 SKIP = ("v_mfma", "v_accvgpr", "v_nop")
 
 
@@ -34,6 +37,8 @@ def disassemble(lib):
 def classify(op, operands):
     if op.startswith(SKIP):
         return None
+    if op.startswith(QUARTER_NAMES):
+        return "quarter"
     if op.endswith(("_e64", "_sdwa", "_dpp")) or op.startswith(HALF_NAMES):
         return "half"
     if op.startswith(MID_NAMES):
@@ -55,7 +60,7 @@ def mix(lib):
             if cur and not cur.startswith("k_"):
                 cur = None
             if cur:
-                out.setdefault(cur, {"valu": 0, "full": 0, "mid": 0, "half": 0})
+                out.setdefault(cur, {"valu": 0, "full": 0, "mid": 0, "half": 0, "quarter": 0})
             continue
         m = re.match(r"^\s+(v_\w+)\s*(.*?)\s*//", line)
         if m and cur:
@@ -64,7 +69,7 @@ def mix(lib):
                 out[cur]["valu"] += 1
                 out[cur][c] += 1
     for k, v in out.items():
-        v["cycles_per_valu"] = round((2 * v["full"] + 3 * v["mid"] + 4 * v["half"]) / max(v["valu"], 1), 3)
+        v["cycles_per_valu"] = round((2 * v["full"] + 3 * v["mid"] + 4 * v["half"] + 8 * v["quarter"]) / max(v["valu"], 1), 3)
     return out
 
 
