@@ -315,7 +315,11 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
     const bool on = X < L.pw;
     uint8_t *base = pyr + (long long)f * g.pyr_bytes;
     const uint8_t *src = base + S.off;
-    uint8_t *dst = base + L.off + X;
+    // Addresses = the level's wave-uniform base (the scalar operand of the loads and stores, saddr form) + a 32-bit offset
+    // (scalar row * pitch + the lane's column: one v_add per access; a level is far below 4 GB) -- round 2's form paid a 64-bit
+    // vector multiply-add per row load (v_mad_i64_i32) and per store (v_mad_u64_u32)
+    uint8_t *dst = base + L.off;
+    const uint32_t ldst = (uint32_t)X;
     uint32_t sel[4], wgt[4];
     int smin = 0x7fff;
     {
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
     // funnel-shifted in registers (two v_alignbyte).  The per-lane unaligned 8-byte load this replaces (a 4.8-byte lane
     // stride, 1-byte alignment) was what bounded the kernel: the address unit serves such a wave-load lane by lane.
     const uint32_t sh = (uint32_t)(smin & 3);
-    src += smin & ~3;
+    const uint32_t lsrc = (uint32_t)(smin & ~3);
     const uint2 *ty = (const uint2 *)taps + L.tapy;
     // Two destination rows per step.  The horizontal pass of a SOURCE row (h[i] = (a0 * p[s0] + a1 * p[s0+1]) >> 4 for the
     // lane's four columns) is what cv::resize keeps in its row buffers: destination row Y+1 usually starts on the source row
@@ -367,8 +371,8 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
     for (int r = 0; r < RR_R; ++r) {
         t[r] = ty[min(y_begin + r, L.ph - 1)];
         u[r].x = u[r].y = u[r].z = 0;
-        if (r == 0 || (int)(t[r].x & 0xffffu) != (int)(t[r - 1].x >> 16)) u[r] = *(const orbx_uint3_a *)(src + (long long)(t[r].x & 0xffffu) * S.pitch);
-        w[r] = *(const orbx_uint3_a *)(src + (long long)(t[r].x >> 16) * S.pitch);
+        if (r == 0 || (int)(t[r].x & 0xffffu) != (int)(t[r - 1].x >> 16)) u[r] = *(const orbx_uint3_a *)(src + (uint32_t)((t[r].x & 0xffffu) * (uint32_t)S.pitch + lsrc));
+        w[r] = *(const orbx_uint3_a *)(src + (uint32_t)((t[r].x >> 16) * (uint32_t)S.pitch + lsrc));
     }
     for (int Y = y_begin; Y < y_end; Y += RR_R) {
         uint2 ct[RR_R];
@@ -381,8 +385,8 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
             for (int r = 0; r < RR_R; ++r) {
                 t[r] = ty[min(Y + RR_R + r, L.ph - 1)];
                 const int s0 = (int)(t[r].x & 0xffffu), s1 = (int)(t[r].x >> 16);
-                if (s0 != last) u[r] = *(const orbx_uint3_a *)(src + (long long)s0 * S.pitch);
-                w[r] = *(const orbx_uint3_a *)(src + (long long)s1 * S.pitch);
+                if (s0 != last) u[r] = *(const orbx_uint3_a *)(src + (uint32_t)((uint32_t)s0 * (uint32_t)S.pitch + lsrc));
+                w[r] = *(const orbx_uint3_a *)(src + (uint32_t)((uint32_t)s1 * (uint32_t)S.pitch + lsrc));
                 last = s1;
             }
         }
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(64 * RR_WPB) void k_pyr_resize_rows(DGeom g, int le
             uint32_t v;
             RR_V(v, h0, h1, ct[r].y & 0xfffu, (ct[r].y >> 16) & 0xfffu)
             pid = (int)(ct[r].x >> 16);
-            if (on && Y + r < y_end) *(uint32_t *)(dst + (long long)(Y + r) * L.pitch) = v;
+            if (on && Y + r < y_end) *(uint32_t *)(dst + (uint32_t)((uint32_t)(Y + r) * (uint32_t)L.pitch + ldst)) = v;
         }
     }
 #undef RR_H

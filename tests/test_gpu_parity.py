@@ -94,6 +94,30 @@ def test_uniform_noise_dense_corners_global_key_path():
     check_stages(ex, orc, 0)
 
 
+@pytest.mark.parametrize("period,amp,noise,lcap", [(16, 100, 0, None), (8, 60, 0, None), (12, 90, 25, None), (16, 100, 12, "64")])
+def test_fast_both_polarity_candidates_and_stack_drain(period, amp, noise, lcap, monkeypatch):
+    """Diagonal stripes with a mid-gray line between them: every pixel of a line has two compass pixels far brighter and two far
+    darker than itself, so it passes BOTH pre-tests of the one-pass corner test (k_fast_rows, fr_round) and fails the polarity it
+    is given -- hundreds of entries per cell group go through the re-run stack, far more than its 128 entries (the drain path),
+    with real corners (stripe ends, noise) in the same rounds.  Compared with the oracle on keypoints, descriptors and every stage."""
+    if lcap:
+        monkeypatch.setenv("ORBX_FAST_LCAP", lcap)
+    h, w = 240, 320
+    yy, xx = np.mgrid[0:h, 0:w]
+    ph = (xx + yy) % period
+    img = np.where(ph == 0, 128, np.where(ph < period // 2, 128 - amp, 128 + amp)).astype(np.int32)
+    ph2 = (xx - yy) % (period + 3)          # a second family of lines the other way in the lower half: crossings are corners
+    img[h // 2:] = np.where(ph2[h // 2:] == 0, 128, img[h // 2:])
+    if noise:
+        img = img + np.random.default_rng(period * 1000 + amp).integers(-noise, noise + 1, (h, w))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    ex = ORBextractor(800, max_cand_per_cell=256)
+    orc = oracle.OracleExtractor(800)
+    out = orc.extract(img, cap=ex.max_keypoints(w, h))
+    assert_frame_equal(ex(img), out, f"stripes {period}/{amp}/{noise}")
+    check_stages(ex, orc, 0)
+
+
 def test_candidate_capacity_is_reported_not_silent():
     rng = np.random.default_rng(43)
     img = rng.integers(0, 256, (240, 320)).astype(np.uint8)

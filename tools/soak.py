@@ -14,10 +14,15 @@ while time.time() - t0 < budget:
     w, h = int(rng.integers(48, 1000)), int(rng.integers(48, 700))
     nf = int(rng.integers(50, 3000)); sf = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.3, 1.5, 2.0])); nl = int(rng.integers(2, 10))
     ini = int(rng.integers(8, 40)); mn = int(rng.integers(2, ini + 1)); fp = int(rng.integers(0, 2))
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 5)
     if kind == 0: img = synth.Scene(w, h, int(rng.integers(0, 1 << 20))).frame(int(rng.integers(0, 50)))
     elif kind == 1: img = rng.integers(0, 256, (h, w), dtype=np.uint8)                                   # dense corners
     elif kind == 2: img = (synth.Scene(w, h, int(rng.integers(0, 1 << 20))).frame(0).astype(np.int32) // 32 * 32).astype(np.uint8)   # plateaus: score ties
+    elif kind == 4:   # diagonal stripes with mid-gray lines: candidates that pass both pre-tests of the one-pass corner test (re-run stack)
+        per, amp, nz = int(rng.integers(6, 24)), int(rng.integers(30, 120)), int(rng.integers(0, 30))
+        yy, xx = np.mgrid[0:h, 0:w]; ph = (xx + yy * int(rng.choice([-1, 1]))) % per
+        t = np.where(ph == 0, 128, np.where(ph < per // 2, 128 - amp, 128 + amp)) + rng.integers(-nz, nz + 1, (h, w))
+        img = np.clip(t, 0, 255).astype(np.uint8)
     else:
         img = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
         for _ in range(int(rng.integers(1, 200))):
