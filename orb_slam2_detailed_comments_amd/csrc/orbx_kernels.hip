@@ -599,9 +599,11 @@ __device__ __forceinline__ void fr_round(const FrCtx &c, const uint16_t *src_mai
         c.score[off + rc] = (uint8_t)(a0 - 1 - f);
     }
     ncorn += __popcll(m);
-    const bool redo = both && !corner && is_main;
-    const unsigned long long mr = orbx_ballot(redo);
+    // (the mask of the re-runs from the two compare masks on the scalar unit; per-lane work only inside the rare branch)
+    unsigned long long mr = orbx_ballot(both) & ~m;
+    if (!FULL) mr &= cm >= 64 ? ~0ull : ((1ull << cm) - 1ull);
     if (mr != 0ull) {
+        const bool redo = both && !corner && is_main;
         if (redo) stack[nredo + orbx_wave_rank(mr)] = code;
         nredo += __popcll(mr);
     }
@@ -715,15 +717,14 @@ __device__ __forceinline__ void fr_nms(const FrCtx &c, const FrCells &gc, const 
         const bool second = col >= gc.iw0;
         const uint8_t *sp = c.score + (ly - 1) * FR_TP + 2 + col;   // top-left of the 3x3 neighbourhood: immediates only
         const int sc = sp[FR_TP + 1];
-        int l0 = sp[0], l1 = sp[FR_TP], l2 = sp[2 * FR_TP];
-        int r0 = sp[2], r1 = sp[FR_TP + 2], r2 = sp[2 * FR_TP + 2];
+        const int l0 = sp[0], l1 = sp[FR_TP], l2 = sp[2 * FR_TP];
+        const int r0 = sp[2], r1 = sp[FR_TP + 2], r2 = sp[2 * FR_TP + 2];
         const int u = sp[1], dn = sp[2 * FR_TP + 1];
         // the score map is shared by the two cells: the neighbours across the seam belong to the other cell's cv::FAST call
+        // (strictly greater than all eight <=> strictly greater than their maximum: one select per side, not one per neighbour)
         const bool seam_l = col == gc.iw0, seam_r = col == gc.iw0 - 1;
-        l0 = seam_l ? 0 : l0; l1 = seam_l ? 0 : l1; l2 = seam_l ? 0 : l2;
-        r0 = seam_r ? 0 : r0; r1 = seam_r ? 0 : r1; r2 = seam_r ? 0 : r2;
-        const bool keep = (int)valid & (int)(sc > l0) & (int)(sc > l1) & (int)(sc > l2) & (int)(sc > r0) & (int)(sc > r1) &
-                          (int)(sc > r2) & (int)(sc > u) & (int)(sc > dn);
+        const int ml = seam_l ? 0 : max(max(l0, l1), l2), mr = seam_r ? 0 : max(max(r0, r1), r2);
+        const bool keep = (int)valid & (int)(sc > max(max(ml, mr), max(u, dn)));
         const unsigned long long m = orbx_ballot(keep), msec = orbx_ballot(keep && second);
         const unsigned long long mfirst = m & ~msec;
         const int slot = second ? ns1 + orbx_wave_rank(msec) : ns0 + orbx_wave_rank(mfirst);   // ordinal inside the cell
@@ -922,8 +923,8 @@ __global__ __launch_bounds__(64, FR_WPS) void k_fast_rows(DGeom g, const OrbxCel
                 const bool cnd = fr_smax((fr_i16)(A - C), (fr_i16)(C - Bm)) > thv;                                      \
                 const unsigned long long m = orbx_ballot(cnd);                                                          \
                 FR_STORE(cnd, m, nb, dummy, code)                                                                       \
-                nb += 2u * (uint32_t)__popcll(m);                                                                       \
-                asm("" : "+s"(nb));   /* ONE scalar cursor: a lane's slot stays mbcnt, mbcnt, v_lshl_add (no split into count + base) */ \
+                { const uint32_t pc_ = (uint32_t)__popcll(m);                                                           \
+                  asm("s_lshl1_add_u32 %0, %1, %0" : "+s"(nb) : "s"(pc_) : "scc"); }   /* nb += 2 * popcount: ONE scalar instruction, ONE scalar cursor (a lane's slot stays mbcnt, mbcnt, v_lshl_add) */ \
                 code += 0x100u;                                                                                         \
                 FR_PROBE()                                                                                              \
             }
@@ -1764,6 +1765,8 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
 #endif
             const uint32_t hbase = (uint32_t)(uintptr_t)(orbx_lds_u16p)hrow + cbias;
             float tv[8];
+            float nb = -b;
+            asm("" : "+v"(nb));   // a register of its own (the compiler would fold the negation back into every product)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -1773,15 +1776,19 @@ __global__ __launch_bounds__(64 * DS_WPB, DS_WPS) void k_describe(DGeom g, const
                     float fy, fx;
                     if (FPM == ORBX_FP_GCC_FMA) {
                         fy = __builtin_fmaf(px, b, py * a);     // vfmadd132ss: x*b + rn(y*a)
-                        fx = __builtin_fmaf(px, a, -(py * b));  // vfmsub132ss: x*a - rn(y*b)
+                        fx = __builtin_fmaf(px, a, py * nb);    // vfmsub132ss: x*a - rn(y*b); -(y*b) = y*(-b) exactly, and a
+                                                                // product by a NEGATED REGISTER is a VOP3 encoding (half rate)
                     } else {
                         fy = px * b + py * a;
-                        fx = px * a - py * b;
+                        fx = px * a + py * nb;
                     }
                     const uint32_t uy = __float_as_uint(fy + 12582912.0f), ux = __float_as_uint(fx + 12582912.0f);
 #if DS_COLFIRST
 #if DS_MFMA
-                    const uint32_t adr = __umul24(ux, 2u * DS_VC) + ((uy << 1) + hbase);   // LDS byte address of HT[ix+18][iy+18]: the tap's window starts here
+                    // LDS byte address of HT[ix+18][iy+18]: the tap's window starts here (two instructions: v_lshl_add + v_mad_u32_u24)
+                    uint32_t ay = (uy << 1) + hbase;
+                    asm("" : "+v"(ay));
+                    const uint32_t adr = __umul24(ux, 2u * DS_VC) + ay;
 #else
                     const uint32_t adr = __umul24(uy, 2u * DS_VC) + ((ux << 1) + hbase);   // LDS byte address of v[iy+18][ix+18]: the tap's window starts here
 #endif
