@@ -457,7 +457,7 @@ __device__ __forceinline__ void orbx_wave_sync() {
 #define FR_WPS 5
 #endif
 #ifndef FR_CCAP
-#define FR_CCAP 256     // corner-list entries per group (see orbx_launch_fast_rows)
+#define FR_CCAP 512     // corner-list entries per group (see orbx_launch_fast_rows): 8 192 bytes of LDS per wave at 640x480, still 20 waves per CU
 #endif
 #ifndef FR_GPW
 #define FR_GPW 2        // groups per wave
@@ -2927,11 +2927,11 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
                            int dbg_stop) {
     if (ngroups <= 0) return;
     lcap = (max(lcap, 64) + 1) & ~1;
-    // LDS per wave decides how many waves a CU holds (the kernel loses 7 % per wave it cannot place): the corner list of a group is
-    // sized for its usual load, FR_CCAP entries (the average group has ~130 corners), not for the work list's worst case -- a
-    // group with more corners than that runs its NMS as the dense rescan of the score map -- and tile / score map are rounded to
-    // 16 bytes, not to four rows: 7 680 bytes at 640x480 (six 1 280-byte granules: 21 waves per CU by LDS, 20 by registers)
-    // instead of 8 896 (seven granules: 18).
+    // LDS per wave decides how many waves a CU holds: the corner list of a group is sized for its usual load, FR_CCAP entries (the
+    // average group has ~130 corners), not for the work list's worst case -- a group with more corners than that runs its NMS as the
+    // dense rescan of the score map -- and tile / score map are rounded to 16 bytes, not to four rows.  At 640x480: 8 192 bytes with
+    // 512 entries = exactly 20 waves per CU, the number the registers allow (round 3, second half: 1.316 / 1.319 -> 1.286 / 1.272 ms
+    // against 256 entries = 7 680 bytes, because fewer groups take the rescan; 640 entries = 8 448 bytes = 19 waves: 1.39-1.41 ms).
     const int ccap = min(lcap, FR_CCAP);
     const size_t map_bytes = ((size_t)max_ch * FR_TP + 15) & ~(size_t)15;
     const size_t smem = 2 * map_bytes + (size_t)2 * lcap + 256 + (size_t)2 * ccap;
