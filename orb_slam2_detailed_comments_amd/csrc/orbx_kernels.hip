@@ -2932,18 +2932,8 @@ void orbx_launch_fast_rows(hipStream_t s, const DGeom &g, int B, const OrbxCell 
     // dense rescan of the score map -- and tile / score map are rounded to 16 bytes, not to four rows.  At 640x480: 8 192 bytes with
     // 512 entries = exactly 20 waves per CU, the number the registers allow (round 3, second half: 1.316 / 1.319 -> 1.286 / 1.272 ms
     // against 256 entries = 7 680 bytes, because fewer groups take the rescan; 640 entries = 8 448 bytes = 19 waves: 1.39-1.41 ms).
-    int ccap = min(lcap, FR_CCAP);
+    const int ccap = min(lcap, FR_CCAP);
     const size_t map_bytes = ((size_t)max_ch * FR_TP + 15) & ~(size_t)15;
-    {
-        // ... but a longer corner list must not cost a wave per CU: 20 waves x 8 192 bytes are the CU's LDS.  Geometries with taller
-        // cells (1241x376: 93.1 k stereo frames/s with 512 entries against 94.2 k with 256) keep the list that still fits, never
-        // less than the 256 entries of round 2's plan.
-        const size_t fixed = 2 * map_bytes + (size_t)2 * lcap + 256;
-        if (fixed + (size_t)2 * ccap > 8192) {
-            const int fit = fixed < 8192 ? (int)((8192 - fixed) / 2) & ~63 : 0;
-            ccap = max(min(ccap, 256), min(ccap, fit));
-        }
-    }
     const size_t smem = 2 * map_bytes + (size_t)2 * lcap + 256 + (size_t)2 * ccap;
     // groups per wave: FR_GPW when the launch has waves to spare (the second group's tile is prefetched while the first
     // is processed); one per wave for small batches, where the serial length of a wave is what the caller waits for
