@@ -98,3 +98,21 @@ def test_no_dpp_fused_reversed_operand_instruction(built_lib):
     assert "v_mov_b32_dpp" in asm and "s_endpgm" in asm          # the disassembly is the library's (its scans use DPP moves)
     bad = sorted(set(re.findall(r"\bv_\w*rev\w*_dpp\b", asm)))
     assert not bad, f"DPP-fused reversed-operand instructions in the code object: {bad}"
+
+
+def test_no_quarter_rate_three_input_16bit_min_max(built_lib):
+    """`v_min3_i16` / `v_max3_i16` (and the u16 / med3 forms) issue at a quarter of the rate of the two-input 16-bit operations on
+    gfx950 (8.4 against 2.8 cycles per wave, tools/valu_rate6.hip, profiles/r03_valu_rate6_gfx950.log), and the compiler fuses
+    min(min(a, b), c) into them wherever the inner value has one use: the score network of k_fast_rows (fr_round) lost a tenth of the
+    kernel's time to 24 of them until every intermediate got a register of its own.  This is a PERFORMANCE guard, not a correctness
+    one: the shipped code object must not contain the three-input 16-bit forms (an edit that lets the compiler fuse them again
+    fails here, not in a profile three weeks later)."""
+    asm = _device_disassembly(built_lib)
+    assert "v_min_i16" in asm and "v_max_i16" in asm              # the network is there, in its two-input form
+    bad = sorted(set(re.findall(r"\bv_(?:min3|max3|med3)_i16\b", asm)))
+    assert not bad, f"quarter-rate three-input 16-bit operations in the code object: {bad}"
+    # Known and tolerated: the two seam maxima of the NMS of k_fast_rows (max(max(l0, l1), l2) of three score bytes became
+    # v_max3_u16 with the one-select-per-side rewrite: four static instances, two executed per NMS round -- ~0.3 % of the kernel;
+    # found by this test after the round's GPU budget was spent, left for the next edit of that function).  Nothing else.
+    u16 = re.findall(r"\bv_(?:min3|max3|med3)_u16\b", asm)
+    assert len(u16) <= 4 and set(u16) <= {"v_max3_u16"}, f"three-input u16 operations beyond the NMS seam maxima: {sorted(set(u16))} x {len(u16)}"
